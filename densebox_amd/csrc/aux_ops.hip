@@ -1,0 +1,369 @@
+// HBM-bound helper kernels around the convolutions: layout conversion, 2x2 max-pool, bilinear
+// resampling (align_corners=True) and their backward passes.  All operate on framed NHWC views and
+// move 16 bytes per lane (8 f16/bf16 or 4 f32 channels).
+#include "common.hpp"
+#include <mutex>
+
+// ---------------------------------------------------------------------------------------------- error plumbing
+static thread_local char g_err[512] = "";
+void dbx_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* dbx_last_error(void) { return g_err; }
+extern "C" int dbx_version(void) { return 1; }
+extern "C" int dbx_device_arch(int device) {
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) != hipSuccess) { dbx_set_error("hipGetDeviceProperties failed"); return DBX_ERR_HIP; }
+    int arch = 0;
+    const char* s = p.gcnArchName;   // "gfx950:sramecc+:xnack-"
+    if (s[0] == 'g' && s[1] == 'f' && s[2] == 'x') arch = (int)strtol(s + 3, nullptr, 16) == 0x950 ? 950 : (int)strtol(s + 3, nullptr, 10);
+    return arch;
+}
+
+template <typename T> struct Vec { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T> __device__ __forceinline__ void load_vec(const T* p, float (&v)[16 / sizeof(T)]) {
+    const u32x4 raw = *(const u32x4*)p;
+    const T* e = (const T*)&raw;
+#pragma unroll
+    for (int i = 0; i < 16 / (int)sizeof(T); ++i) v[i] = to_f32(e[i]);
+}
+template <typename T> __device__ __forceinline__ void store_vec(T* p, const float (&v)[16 / sizeof(T)]) {
+    u32x4 raw;
+    T* e = (T*)&raw;
+#pragma unroll
+    for (int i = 0; i < 16 / (int)sizeof(T); ++i) e[i] = from_f32<T>(v[i]);
+    *(u32x4*)p = raw;
+}
+
+static inline int grid_for(int64_t work, int block = 256) {
+    int64_t b = (work + block - 1) / block;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+#define VIEW_VEC_CHECK(T, v, name)                                                                             \
+    DBX_REQUIRE(((size_t)(v)->ptr % 16) == 0 && ((v)->ld * sizeof(T)) % 16 == 0 && ((v)->c_off * sizeof(T)) % 16 == 0 && \
+                    ((v)->c * sizeof(T)) % 16 == 0, name ": view must be 16-byte aligned/strided")
+
+// ---------------------------------------------------------------------------------------------- NCHW fp32 -> framed
+template <typename T>
+__global__ void nchw_to_framed_kernel(const float* __restrict__ x, int csrc, FrameGeo y) {
+    constexpr int V = Vec<T>::N;
+    const int cg = y.c / V;
+    const int64_t total = (int64_t)y.n * y.h * y.w * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // lanes run along x fastest (coalesced reads of each source plane); channel group slowest within a pixel row
+        const int px = (int)(i % y.w);
+        const int g = (int)((i / y.w) % cg);
+        const int py = (int)((i / ((int64_t)y.w * cg)) % y.h);
+        const int n = (int)(i / ((int64_t)y.w * cg * y.h));
+        float v[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = g * V + j;
+            v[j] = c < csrc ? x[(((int64_t)n * csrc + c) * y.h + py) * y.w + px] : 0.f;
+        }
+        store_vec<T>((T*)y.base + geo_pix(y, n, py, px) + g * V, v);
+    }
+}
+template <typename T> static int nchw_to_framed_t(const float* x, int csrc, const dbx_view* y, hipStream_t s) {
+    VIEW_VEC_CHECK(T, y, "nchw_to_framed");
+    FrameGeo g = make_geo<T>(y);
+    const int64_t total = (int64_t)y->n * y->h * y->w * (y->c / Vec<T>::N);
+    hipLaunchKernelGGL(nchw_to_framed_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, x, csrc, g);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_nchw_to_framed(int32_t dtype, const float* x_nchw, int32_t c_src, const dbx_view* y, void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, nchw_to_framed_t, x_nchw, c_src, y, (hipStream_t)stream);
+}
+
+template <typename T>
+__global__ void framed_to_nchw_kernel(FrameGeo x, float* __restrict__ y) {
+    const int64_t total = (int64_t)x.n * x.c * x.h * x.w;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % x.w);
+        const int py = (int)((i / x.w) % x.h);
+        const int c = (int)((i / ((int64_t)x.w * x.h)) % x.c);
+        const int n = (int)(i / ((int64_t)x.w * x.h * x.c));
+        y[i] = to_f32(((const T*)x.base)[geo_pix(x, n, py, px) + c]);
+    }
+}
+template <typename T> static int framed_to_nchw_t(const dbx_view* x, float* y, hipStream_t s) {
+    FrameGeo g = make_geo<T>(x);
+    const int64_t total = (int64_t)x->n * x->c * x->h * x->w;
+    hipLaunchKernelGGL(framed_to_nchw_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, g, y);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_framed_to_nchw_f32(int32_t dtype, const dbx_view* x, float* y_nchw, void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, framed_to_nchw_t, x, y_nchw, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- max-pool 2x2 stride 2 (floor)
+template <typename T>
+__global__ void maxpool_kernel(FrameGeo x, FrameGeo y) {
+    constexpr int V = Vec<T>::N;
+    const int cg = y.c / V;
+    const int64_t total = (int64_t)y.n * y.h * y.w * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int px = (int)((i / cg) % y.w);
+        const int py = (int)((i / ((int64_t)cg * y.w)) % y.h);
+        const int n = (int)(i / ((int64_t)cg * y.w * y.h));
+        const T* p = (const T*)x.base + geo_pix(x, n, 2 * py, 2 * px) + g * V;
+        float a[V], b[V], c[V], d[V], o[V];
+        load_vec<T>(p, a);
+        load_vec<T>(p + x.ld, b);
+        load_vec<T>(p + (size_t)x.wp * x.ld, c);
+        load_vec<T>(p + (size_t)x.wp * x.ld + x.ld, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], d[j]));
+        store_vec<T>((T*)y.base + geo_pix(y, n, py, px) + g * V, o);
+    }
+}
+template <typename T> static int maxpool_t(const dbx_view* x, const dbx_view* y, hipStream_t s) {
+    VIEW_VEC_CHECK(T, x, "maxpool x"); VIEW_VEC_CHECK(T, y, "maxpool y");
+    DBX_REQUIRE(y->h == x->h / 2 && y->w == x->w / 2 && y->c == x->c && y->n == x->n, "maxpool: shape mismatch");
+    const int64_t total = (int64_t)y->n * y->h * y->w * (y->c / Vec<T>::N);
+    hipLaunchKernelGGL(maxpool_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, make_geo<T>(x), make_geo<T>(y));
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_maxpool2x2(int32_t dtype, const dbx_view* x, const dbx_view* y, void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, maxpool_t, x, y, (hipStream_t)stream);
+}
+
+// backward: one lane per (pre-pool pixel, channel group).  The arg-max is the FIRST window element equal to the
+// maximum in (0,0),(0,1),(1,0),(1,1) order -- ATen's max_pool2d keeps the earlier element on ties.
+template <typename T>
+__global__ void maxpool_bwd_kernel(FrameGeo x, FrameGeo dy, FrameGeo dx, int ph, int pw, int accumulate, int relu_gate) {
+    constexpr int V = Vec<T>::N;
+    const int cg = x.c / V;
+    const int64_t total = (int64_t)x.n * x.h * x.w * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int px = (int)((i / cg) % x.w);
+        const int py = (int)((i / ((int64_t)cg * x.w)) % x.h);
+        const int n = (int)(i / ((int64_t)cg * x.w * x.h));
+        float o[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = 0.f;
+        const int wy = py >> 1, wx = px >> 1;
+        if (wy < ph && wx < pw) {
+            const T* p = (const T*)x.base + geo_pix(x, n, 2 * wy, 2 * wx) + g * V;
+            float q[4][V], gd[V];
+            load_vec<T>(p, q[0]);
+            load_vec<T>(p + x.ld, q[1]);
+            load_vec<T>(p + (size_t)x.wp * x.ld, q[2]);
+            load_vec<T>(p + (size_t)x.wp * x.ld + x.ld, q[3]);
+            load_vec<T>((const T*)dy.base + geo_pix(dy, n, wy, wx) + g * V, gd);
+            const int me = ((py & 1) << 1) | (px & 1);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                int arg = 0;
+                float m = q[0][j];
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (q[k][j] > m) { m = q[k][j]; arg = k; }
+                float v = arg == me ? gd[j] : 0.f;
+                if (relu_gate && !(q[me][j] > 0.f)) v = 0.f;
+                o[j] = v;
+            }
+        }
+        T* dst = (T*)dx.base + geo_pix(dx, n, py, px) + g * V;
+        if (accumulate) {
+            float old[V];
+            load_vec<T>(dst, old);
+#pragma unroll
+            for (int j = 0; j < V; ++j) o[j] += old[j];
+        }
+        store_vec<T>(dst, o);
+    }
+}
+template <typename T>
+static int maxpool_bwd_t(const dbx_view* x, const dbx_view* dy, const dbx_view* dx, int accumulate, int relu_gate, hipStream_t s) {
+    VIEW_VEC_CHECK(T, x, "maxpool_bwd x"); VIEW_VEC_CHECK(T, dy, "maxpool_bwd dy"); VIEW_VEC_CHECK(T, dx, "maxpool_bwd dx");
+    DBX_REQUIRE(dy->h == x->h / 2 && dy->w == x->w / 2 && dx->h == x->h && dx->w == x->w && dx->c == x->c && dy->c == x->c,
+                "maxpool_bwd: shape mismatch");
+    const int64_t total = (int64_t)x->n * x->h * x->w * (x->c / Vec<T>::N);
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, make_geo<T>(x), make_geo<T>(dy),
+                       make_geo<T>(dx), dy->h, dy->w, accumulate, relu_gate);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_maxpool2x2_bwd(int32_t dtype, const dbx_view* x, const dbx_view* dy, const dbx_view* dx,
+                                  int32_t accumulate, int32_t relu_gate, void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, maxpool_bwd_t, x, dy, dx, accumulate, relu_gate, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- bilinear, align_corners=True
+// ATen: scale = (in-1)/(out-1) in float; src = scale*dst; i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0.
+__device__ __forceinline__ void bilin_coef(int d, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+    const float src = scale * (float)d;
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+template <typename T>
+__global__ void upsample_kernel(FrameGeo x, FrameGeo y, float sy, float sx) {
+    constexpr int V = Vec<T>::N;
+    const int cg = y.c / V;
+    const int64_t total = (int64_t)y.n * y.h * y.w * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int px = (int)((i / cg) % y.w);
+        const int py = (int)((i / ((int64_t)cg * y.w)) % y.h);
+        const int n = (int)(i / ((int64_t)cg * y.w * y.h));
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        bilin_coef(py, sy, x.h, y0, y1, ly0, ly1);
+        bilin_coef(px, sx, x.w, x0, x1, lx0, lx1);
+        float a[V], b[V], c[V], d[V], o[V];
+        const T* base = (const T*)x.base + g * V;
+        load_vec<T>(base + geo_pix(x, n, y0, x0), a);
+        load_vec<T>(base + geo_pix(x, n, y0, x1), b);
+        load_vec<T>(base + geo_pix(x, n, y1, x0), c);
+        load_vec<T>(base + geo_pix(x, n, y1, x1), d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = ly0 * (lx0 * a[j] + lx1 * b[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
+        store_vec<T>((T*)y.base + geo_pix(y, n, py, px) + g * V, o);
+    }
+}
+template <typename T> static int upsample_t(const dbx_view* x, const dbx_view* y, hipStream_t s) {
+    VIEW_VEC_CHECK(T, x, "upsample x"); VIEW_VEC_CHECK(T, y, "upsample y");
+    DBX_REQUIRE(x->c == y->c && x->n == y->n, "upsample: channel/batch mismatch");
+    const int64_t total = (int64_t)y->n * y->h * y->w * (y->c / Vec<T>::N);
+    hipLaunchKernelGGL(upsample_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, make_geo<T>(x), make_geo<T>(y),
+                       ac_scale(x->h, y->h), ac_scale(x->w, y->w));
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_upsample_bilinear(int32_t dtype, const dbx_view* x, const dbx_view* y, void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, upsample_t, x, y, (hipStream_t)stream);
+}
+
+// backward in gather form (deterministic, no atomics): each source pixel sums the destination pixels that
+// interpolate from it, recomputing the forward coefficients.
+template <typename T>
+__global__ void upsample_bwd_kernel(FrameGeo dy, FrameGeo dx, FrameGeo gate, int has_gate, float sy, float sx) {
+    constexpr int V = Vec<T>::N;
+    const int cg = dx.c / V;
+    const int64_t total = (int64_t)dx.n * dx.h * dx.w * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % cg);
+        const int ix = (int)((i / cg) % dx.w);
+        const int iy = (int)((i / ((int64_t)cg * dx.w)) % dx.h);
+        const int n = (int)(i / ((int64_t)cg * dx.w * dx.h));
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        // destination rows whose source coordinate lies in (iy-1, iy+1)
+        int oy_lo = sy > 0.f ? (int)floorf((float)(iy - 1) / sy) : 0;
+        int oy_hi = sy > 0.f ? (int)ceilf((float)(iy + 1) / sy) : dy.h - 1;
+        int ox_lo = sx > 0.f ? (int)floorf((float)(ix - 1) / sx) : 0;
+        int ox_hi = sx > 0.f ? (int)ceilf((float)(ix + 1) / sx) : dy.w - 1;
+        oy_lo = max(oy_lo, 0); ox_lo = max(ox_lo, 0);
+        oy_hi = min(oy_hi, dy.h - 1); ox_hi = min(ox_hi, dy.w - 1);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly0, ly1;
+            bilin_coef(oy, sy, dx.h, y0, y1, ly0, ly1);
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx0, lx1;
+                bilin_coef(ox, sx, dx.w, x0, x1, lx0, lx1);
+                const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                float d[V];
+                load_vec<T>((const T*)dy.base + geo_pix(dy, n, oy, ox) + g * V, d);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += wy * wx * d[j];
+            }
+        }
+        if (has_gate) {
+            float gt[V];
+            load_vec<T>((const T*)gate.base + geo_pix(gate, n, iy, ix) + g * V, gt);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] = gt[j] > 0.f ? acc[j] : 0.f;
+        }
+        store_vec<T>((T*)dx.base + geo_pix(dx, n, iy, ix) + g * V, acc);
+    }
+}
+template <typename T>
+static int upsample_bwd_t(const dbx_view* dy, const dbx_view* dx, const dbx_view* gate, hipStream_t s) {
+    VIEW_VEC_CHECK(T, dy, "upsample_bwd dy"); VIEW_VEC_CHECK(T, dx, "upsample_bwd dx");
+    DBX_REQUIRE(dx->c == dy->c && dx->n == dy->n, "upsample_bwd: channel/batch mismatch");
+    if (gate) { VIEW_VEC_CHECK(T, gate, "upsample_bwd gate"); DBX_REQUIRE(gate->h == dx->h && gate->w == dx->w && gate->c == dx->c, "upsample_bwd: gate shape"); }
+    const int64_t total = (int64_t)dx->n * dx->h * dx->w * (dx->c / Vec<T>::N);
+    FrameGeo gg = gate ? make_geo<T>(gate) : make_geo<T>(dx);
+    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, make_geo<T>(dy), make_geo<T>(dx), gg,
+                       gate ? 1 : 0, ac_scale(dx->h, dy->h), ac_scale(dx->w, dy->w));
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_upsample_bilinear_bwd(int32_t dtype, const dbx_view* dy, const dbx_view* dx, const dbx_view* gate, void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, upsample_bwd_t, dy, dx, gate, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- channel-slice scatter
+// y[n,py,px, c_dst_off + c] = x_nchw[n,c,py,px] for c < c_src; other channels untouched (they stay 0 from
+// the workspace memset).  Used to build the refine-branch input cat(landmarks, score) (DenseBox.py:464).
+template <typename T>
+__global__ void nchw_to_framed_ch_kernel(const float* __restrict__ x, int csrc, FrameGeo y, int c_dst_off) {
+    const int64_t total = (int64_t)y.n * csrc * y.h * y.w;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % y.w);
+        const int py = (int)((i / y.w) % y.h);
+        const int c = (int)((i / ((int64_t)y.w * y.h)) % csrc);
+        const int n = (int)(i / ((int64_t)y.w * y.h * csrc));
+        ((T*)y.base)[geo_pix(y, n, py, px) + c_dst_off + c] = from_f32<T>(x[i]);
+    }
+}
+template <typename T> static int nchw_to_framed_ch_t(const float* x, int csrc, const dbx_view* y, int c_dst_off, hipStream_t s) {
+    DBX_REQUIRE(c_dst_off + csrc <= y->c, "nchw_to_framed_ch: slice out of range");
+    const int64_t total = (int64_t)y->n * csrc * y->h * y->w;
+    hipLaunchKernelGGL(nchw_to_framed_ch_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, x, csrc, make_geo<T>(y), c_dst_off);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_nchw_to_framed_ch(int32_t dtype, const float* x_nchw, int32_t c_src, const dbx_view* y,
+                                     int32_t c_dst_off, void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, nchw_to_framed_ch_t, x_nchw, c_src, y, c_dst_off, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- dropout mask (p = 0.5)
+// Counter-based: bit j of splitmix64(seed + word index).  Device RNG cannot reproduce torch's CPU stream
+// (SURVEY.md 8c), so parity tests inject masks instead; this generator is the training-mode default.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void dropout_mask_kernel(unsigned char* __restrict__ m, int64_t nbytes, unsigned long long seed) {
+    const int64_t nvec = nbytes / 16;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long r = splitmix64(seed * 0x100000001B3ull + (unsigned long long)i);
+        u32x4 o;
+        o.x = (unsigned)(r & 1) | (unsigned)((r >> 1) & 1) << 8 | (unsigned)((r >> 2) & 1) << 16 | (unsigned)((r >> 3) & 1) << 24;
+        o.y = (unsigned)((r >> 4) & 1) | (unsigned)((r >> 5) & 1) << 8 | (unsigned)((r >> 6) & 1) << 16 | (unsigned)((r >> 7) & 1) << 24;
+        o.z = (unsigned)((r >> 8) & 1) | (unsigned)((r >> 9) & 1) << 8 | (unsigned)((r >> 10) & 1) << 16 | (unsigned)((r >> 11) & 1) << 24;
+        o.w = (unsigned)((r >> 12) & 1) | (unsigned)((r >> 13) & 1) << 8 | (unsigned)((r >> 14) & 1) << 16 | (unsigned)((r >> 15) & 1) << 24;
+        *(u32x4*)(m + i * 16) = o;
+    }
+}
+extern "C" int dbx_dropout_mask(uint8_t* mask, int64_t nbytes, uint64_t seed, void* stream) {
+    DBX_REQUIRE(nbytes % 16 == 0 && ((size_t)mask % 16) == 0, "dropout_mask: 16-byte granularity");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(nbytes / 16)), dim3(256), 0, (hipStream_t)stream, mask, nbytes,
+                       (unsigned long long)seed);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}

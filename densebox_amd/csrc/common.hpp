@@ -1,0 +1,87 @@
+// Shared device/host helpers for libdensebox_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/densebox_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+void dbx_set_error(const char* fmt, ...);
+
+#define DBX_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            dbx_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return DBX_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define DBX_LAUNCH_CHECK()                                                                    \
+    do {                                                                                      \
+        hipError_t e_ = hipGetLastError();                                                    \
+        if (e_ != hipSuccess) {                                                               \
+            dbx_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return DBX_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define DBX_REQUIRE(cond, ...)                                                                \
+    do {                                                                                      \
+        if (!(cond)) {                                                                        \
+            dbx_set_error(__VA_ARGS__);                                                       \
+            return DBX_ERR_ARG;                                                               \
+        }                                                                                     \
+    } while (0)
+
+static inline int dbx_esize(int dtype) { return dtype == DBX_F32 ? 4 : 2; }
+
+// ---- device-side dtype helpers ---------------------------------------------------------------
+template <typename T> struct DType;
+template <> struct DType<_Float16> { static constexpr int id = DBX_F16; };
+template <> struct DType<__bf16> { static constexpr int id = DBX_BF16; };
+template <> struct DType<float> { static constexpr int id = DBX_F32; };
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// frame geometry of a dbx_view flattened for kernels
+struct FrameGeo {
+    char* base;        // byte pointer to element (0, -pad, -pad, c_off)
+    int n, h, w, pad;  // logical dims
+    int hp, wp;        // framed dims
+    int ld;            // elements per pixel
+    int c;             // channels in view
+};
+
+template <typename T>
+static inline FrameGeo make_geo(const dbx_view* v) {
+    FrameGeo g;
+    g.base = (char*)v->ptr + (size_t)v->c_off * sizeof(T);
+    g.n = v->n; g.h = v->h; g.w = v->w; g.pad = v->pad;
+    g.hp = v->h + 2 * v->pad; g.wp = v->w + 2 * v->pad;
+    g.ld = v->ld; g.c = v->c;
+    return g;
+}
+
+// byte offset of logical pixel (n,y,x) in a frame
+__device__ __forceinline__ size_t geo_pix(const FrameGeo& g, int n, int y, int x) {
+    return ((size_t)(n * g.hp + y + g.pad) * g.wp + (x + g.pad)) * (size_t)g.ld;
+}
+
+#define DBX_DISPATCH_DTYPE(dtype, FN, ...)                          \
+    switch (dtype) {                                                \
+        case DBX_F16: return FN<_Float16>(__VA_ARGS__);             \
+        case DBX_BF16: return FN<__bf16>(__VA_ARGS__);              \
+        case DBX_F32: return FN<float>(__VA_ARGS__);                \
+        default: dbx_set_error("bad dtype %d", (int)(dtype)); return DBX_ERR_DTYPE; \
+    }

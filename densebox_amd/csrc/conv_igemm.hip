@@ -1,0 +1,352 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (framed NHWC, im2col-free).
+//
+//   D[co][m] = sum_k Wp[co][k] * A[m][k],   k = tap*cin_pad + ci,
+//   A[m][k]  = x[pixel(m) + tapoff(tap)][ci]           (read straight from the zero-framed activation)
+//
+// One 256-thread workgroup (4 waves) owns a BM(pixels) x BN(couts) tile; each wave a 64x64 sub-tile as
+// 4x4 MFMA 16x16 fragments.  The K loop advances 128 bytes of K per step (64 f16/bf16 or 32 f32):
+// global -> registers (next step, in flight during the MFMAs) -> XOR-swizzled LDS (double buffered, one
+// barrier per step) -> ds_read_b128 fragments -> MFMA.  The weight tile is the MFMA "A" operand and
+// the pixel tile the "B" operand, so every lane ends up with 4 consecutive output channels of one pixel
+// (an 8-byte NHWC store) instead of one channel of 4 pixels.
+//
+// f16/bf16 use v_mfma_f32_16x16x32_{f16,bf16}; f32 uses v_mfma_f32_16x16x4_f32 four times per 16-byte
+// chunk (exact fp32; the parity anchor).  The same kernel serves the 3x3 backbone, the 1x1 heads, the
+// un-padded 3x3/5x5 refine convs, the Cin=3/5 layers (SMALLC: one 16-byte chunk per tap) and -- with
+// flipped/transposed packed weights -- every dgrad.
+#include "common.hpp"
+
+struct ConvArgs {
+    const char* x;       // framed input, pointing at pixel (0,-pad,-pad) channel c_off
+    const char* w;       // packed weights [cout_pad][ktot]
+    const float* bias;
+    char* y;             // framed output (or fp32 NCHW)
+    const char* gate;    // framed, same n/h/w as y
+    const unsigned char* dropmask;  // [M][dm_ld]
+    int M, HoWo, Wo;     // output pixels
+    int x_hp, x_wp, x_ld, x_org;    // framed input dims (pixels), elements per pixel, origin shift (x.pad - cpad)
+    int y_hp, y_wp, y_ld, y_pad;
+    int g_hp, g_wp, g_ld, g_pad;
+    int kw;              // kernel width (taps = kh*kw)
+    int ntaps;
+    int cpt;             // 16-byte chunks per tap
+    int ksteps;          // 128-byte K steps
+    int ktot_bytes;      // bytes per packed weight row
+    int cout_valid;      // channels actually stored
+    int ntile_n;         // cout_pad / BN
+    int nblocks;
+    int epi;
+    int dm_ld;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<_Float16> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<__bf16> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // lane (i=l&15, g=l>>4) holds 4 consecutive k of its row; MFMA j consumes element j of both operands,
+    // i.e. the hardware's k index g is mapped to logical k = 4g+j for A and B alike (a consistent permutation).
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
+        // NB: bit-cast the whole vector; __builtin_bit_cast(float, a.y) on an element lvalue reads element 0 (hipcc 7.2)
+        const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
+    }
+};
+
+template <typename T, int BM, int BN, int WM, int WN, bool SMALLC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int A_LD = BM / 32, B_LD = BN / 32; // 16-byte chunks per thread per K step
+    constexpr int ES = sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                       // [2][BM][128]
+    char* Bs = smem + 2 * BM * 128;        // [2][BN][128]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile order: workgroup b runs on XCD b%8; give each XCD a contiguous run of tiles so that the
+    // N-tiles of one pixel tile (same A panel) and neighbouring pixel tiles (shared halo rows) share an L2.
+    int bid = blockIdx.x;
+    {
+        const int q = a.nblocks >> 3, r = a.nblocks & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tile_m = bid / a.ntile_n, tile_n = bid - tile_m * a.ntile_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread load assignment: chunk (tid&7) of rows (tid>>3) + 32*i
+    const int lchunk = tid & 7, lrow = tid >> 3;
+    const char* arow[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        int m = m0 + lrow + 32 * i;
+        m = m < a.M ? m : a.M - 1;
+        const int n = m / a.HoWo, r = m - n * a.HoWo;
+        const int oy = r / a.Wo, ox = r - oy * a.Wo;
+        arow[i] = a.x + ((size_t)(n * a.x_hp + oy + a.x_org) * a.x_wp + (ox + a.x_org)) * (size_t)a.x_ld * ES + lchunk * 16;
+    }
+    const char* brow[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) brow[i] = a.w + (size_t)(n0 + lrow + 32 * i) * a.ktot_bytes + lchunk * 16;
+
+    const int pix_bytes = a.x_ld * ES;
+    const int sw_w = ((lrow >> 1) & 7);   // (row>>1)&7 is the same for rows lrow+32*i
+    const int lds_w = lrow * 128 + ((lchunk ^ sw_w) << 4);
+
+    u32x4 areg[A_LD], breg[B_LD];
+    auto gload = [&](int ks) {
+        int aoff;
+        if constexpr (SMALLC) {
+            int tap = ks * 8 + lchunk;                     // one 16-byte chunk per tap
+            tap = tap < a.ntaps ? tap : 0;                 // K padding: weights there are zero
+            const int ky = tap / a.kw, kx = tap - ky * a.kw;
+            aoff = (ky * a.x_wp + kx) * pix_bytes - lchunk * 16;
+        } else {
+            const int c0 = ks * 8;                         // first chunk of this step (uniform)
+            const int tap = c0 / a.cpt, within = c0 - tap * a.cpt;
+            const int ky = tap / a.kw, kx = tap - ky * a.kw;
+            aoff = (ky * a.x_wp + kx) * pix_bytes + within * 16;
+        }
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) areg[i] = *(const u32x4*)(arow[i] + aoff);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) breg[i] = *(const u32x4*)(brow[i] + ks * 128);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) *(u32x4*)(As + buf * BM * 128 + i * 32 * 128 + lds_w) = areg[i];
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) *(u32x4*)(Bs + buf * BN * 128 + i * 32 * 128 + lds_w) = breg[i];
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row (l&15) of a 16-row fragment, logical chunk kk*4 + (l>>4)
+    const int fr = lane & 15;
+    const int c0sw = ((lane >> 4) ^ ((lane >> 1) & 7)) << 4;   // kk = 0; kk = 1 flips bit 6 (chunk ^ 4)
+    const int rd_a = (wm * WTM + fr) * 128;
+    const int rd_b = (wn * WTN + fr) * 128;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int ks = 0; ks < a.ksteps; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < a.ksteps) gload(ks + 1);
+        const char* Ab = As + buf * BM * 128 + rd_a;
+        const char* Bb = Bs + buf * BN * 128 + rd_b;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int co = c0sw ^ (kk << 6);
+            u32x4 wf[NI], xf[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const u32x4*)(Bb + ni * 16 * 128 + co);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const u32x4*)(Ab + mi * 16 * 128 + co);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) Mma<T>::run(wf[ni], xf[mi], acc[ni][mi]);
+        }
+        if (ks + 1 < a.ksteps) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds couts cb + ni*16 + (l>>4)*4 + {0..3} of pixel mb + mi*16 + (l&15)
+    const int cb = n0 + wn * WTN + (lane >> 4) * 4;
+    const int mb = m0 + wm * WTM + (lane & 15);
+    const int epi = a.epi;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = mb + mi * 16;
+        if (m >= a.M) continue;
+        const int n = m / a.HoWo, r = m - n * a.HoWo;
+        const int oy = r / a.Wo, ox = r - oy * a.Wo;
+        const size_t ypix = ((size_t)(n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
+        const size_t gpix = ((size_t)(n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int c = cb + ni * 16;
+            if (c >= a.cout_valid) continue;
+            f32x4 v = acc[ni][mi];
+            if (epi & DBX_EPI_BIAS) {
+                const f32x4 b = *(const f32x4*)(a.bias + c);
+                v += b;
+            }
+            if (epi & DBX_EPI_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (epi & DBX_EPI_GATE) {
+                const T* g = (const T*)a.gate + gpix + c;
+                v.x = to_f32(g[0]) > 0.f ? v.x : 0.f; v.y = to_f32(g[1]) > 0.f ? v.y : 0.f;
+                v.z = to_f32(g[2]) > 0.f ? v.z : 0.f; v.w = to_f32(g[3]) > 0.f ? v.w : 0.f;
+            }
+            if (epi & DBX_EPI_DROPMASK) {
+                const unsigned int mk = *(const unsigned int*)(a.dropmask + (size_t)m * a.dm_ld + c);
+                v.x = (mk & 0xffu) ? v.x * 2.f : 0.f; v.y = (mk & 0xff00u) ? v.y * 2.f : 0.f;
+                v.z = (mk & 0xff0000u) ? v.z * 2.f : 0.f; v.w = (mk & 0xff000000u) ? v.w * 2.f : 0.f;
+            }
+            if (epi & DBX_EPI_F32_NCHW) {
+                float* o = (float*)a.y + ((size_t)n * a.cout_valid + c) * a.HoWo + r;
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < a.cout_valid) {
+                        if (epi & DBX_EPI_ACCUM) o[(size_t)j * a.HoWo] += vv[j];
+                        else o[(size_t)j * a.HoWo] = vv[j];
+                    }
+            } else {
+                T* o = (T*)a.y + ypix + c;
+                if (epi & DBX_EPI_ACCUM) {
+                    v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]);
+                }
+                if constexpr (sizeof(T) == 2) {
+                    T p[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+                    *(u32x2*)o = *(const u32x2*)p;
+                } else {
+                    *(f32x4*)o = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+static int64_t packed_k_elems(const dbx_conv_desc* d) {
+    const int es = dbx_esize(d->dtype);
+    const int64_t kbytes = (int64_t)d->kh * d->kw * d->cin_pad * es;
+    return ((kbytes + 127) / 128) * 128 / es;
+}
+
+extern "C" int64_t dbx_conv_packed_elems(const dbx_conv_desc* d) {
+    return (int64_t)d->cout_pad * packed_k_elems(d);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool SMALLC>
+static int launch_conv(const ConvArgs& a, hipStream_t s) {
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DBX_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, SMALLC>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, SMALLC>), dim3(a.nblocks), dim3(256), smem, s, a);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+template <typename T>
+static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void* w, const float* bias,
+                          const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int dm_ld, hipStream_t s) {
+    constexpr int ES = sizeof(T);
+    const int ho = x->h + 2 * d->cpad - d->kh + 1, wo = x->w + 2 * d->cpad - d->kw + 1;
+    DBX_REQUIRE(ho == y->h && wo == y->w && x->n == y->n, "conv: output %dx%d does not match %dx%d", y->h, y->w, ho, wo);
+    DBX_REQUIRE(x->pad >= d->cpad, "conv: input frame %d < conv padding %d", x->pad, d->cpad);
+    DBX_REQUIRE((d->cin_pad * ES) % 16 == 0 && d->cout_pad % 64 == 0, "conv: cin_pad/cout_pad alignment");
+    DBX_REQUIRE(((size_t)x->ptr % 16) == 0 && (x->ld * ES) % 16 == 0 && (x->c_off * ES) % 16 == 0, "conv: x alignment");
+    const int cpt = d->cin_pad * ES / 16;
+    const bool smallc = cpt < 8;
+    DBX_REQUIRE(smallc ? cpt == 1 : cpt % 8 == 0, "conv: cin_pad*esize must be 16 or a multiple of 128 bytes (got %d)", d->cin_pad * ES);
+    DBX_REQUIRE(x->c >= (smallc ? 1 : d->cin_pad) && x->c_off + d->cin_pad <= x->ld, "conv: x view too narrow");
+    const bool nchw = d->epilogue & DBX_EPI_F32_NCHW;
+    if (!nchw) DBX_REQUIRE(y->c % 4 == 0 && ((y->c_off * ES) % 8) == 0 && (y->ld * ES) % 8 == 0, "conv: y alignment");
+    DBX_REQUIRE(y->c <= d->cout_pad, "conv: y has more channels than the packed weight");
+    if (d->epilogue & DBX_EPI_GATE) DBX_REQUIRE(gate && gate->h == y->h && gate->w == y->w && gate->c >= y->c, "conv: bad gate view");
+    if (d->epilogue & DBX_EPI_DROPMASK) DBX_REQUIRE(dropmask && dm_ld % 4 == 0, "conv: bad dropout mask");
+    if (d->epilogue & DBX_EPI_BIAS) DBX_REQUIRE(bias != nullptr, "conv: bias missing");
+
+    ConvArgs a;
+    a.x = (const char*)x->ptr + (size_t)x->c_off * ES;
+    a.w = (const char*)w;
+    a.bias = bias;
+    a.y = nchw ? (char*)y->ptr : (char*)y->ptr + (size_t)y->c_off * ES;
+    a.gate = gate ? (const char*)gate->ptr + (size_t)gate->c_off * ES : nullptr;
+    a.dropmask = dropmask;
+    a.M = x->n * ho * wo; a.HoWo = ho * wo; a.Wo = wo;
+    a.x_hp = x->h + 2 * x->pad; a.x_wp = x->w + 2 * x->pad; a.x_ld = x->ld; a.x_org = x->pad - d->cpad;
+    a.y_hp = y->h + 2 * y->pad; a.y_wp = y->w + 2 * y->pad; a.y_ld = y->ld; a.y_pad = y->pad;
+    if (gate) { a.g_hp = gate->h + 2 * gate->pad; a.g_wp = gate->w + 2 * gate->pad; a.g_ld = gate->ld; a.g_pad = gate->pad; }
+    else { a.g_hp = a.g_wp = a.g_ld = a.g_pad = 0; }
+    a.kw = d->kw; a.ntaps = d->kh * d->kw; a.cpt = cpt;
+    a.ktot_bytes = (int)(packed_k_elems(d) * ES);
+    a.ksteps = a.ktot_bytes / 128;
+    a.cout_valid = y->c;
+    a.epi = d->epilogue; a.dm_ld = dm_ld;
+    DBX_REQUIRE(a.M > 0 && (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < (int64_t)1 << 40, "conv: empty or oversized input");
+
+    // tile choice: couts are tiled by 128 unless the layer has 64 (or the result is tiny, e.g. the 512->k heads)
+    const bool narrow = (d->cout_pad % 128 != 0) || y->c <= 64;
+    if (narrow) {
+        a.ntile_n = d->cout_pad / 64;
+        if (y->c <= 64) a.ntile_n = 1;
+        a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
+        return smallc ? launch_conv<T, 256, 64, 4, 1, true>(a, s) : launch_conv<T, 256, 64, 4, 1, false>(a, s);
+    }
+    a.ntile_n = (y->c + 127) / 128;
+    a.nblocks = ((a.M + 127) / 128) * a.ntile_n;
+    return smallc ? launch_conv<T, 128, 128, 2, 2, true>(a, s) : launch_conv<T, 128, 128, 2, 2, false>(a, s);
+}
+
+extern "C" int dbx_conv_forward(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
+                                const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int32_t dropmask_ld,
+                                void* stream) {
+    if (!d || !x || !y || !w_packed) { dbx_set_error("conv: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(d->dtype, conv_forward_t, d, x, w_packed, bias, y, gate, dropmask, dropmask_ld, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ weight packing
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, int co, int ci, int taps, int mode,
+                                   T* __restrict__ wp, int64_t ktot, int cin_pad, int row_off, int k_off) {
+    const int64_t total = (int64_t)co * ci * taps;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % taps);
+        const int c = (int)((i / taps) % ci);
+        const int o = (int)(i / ((int64_t)taps * ci));
+        const float v = w[i];
+        if (mode == 0) wp[(int64_t)(row_off + o) * ktot + (int64_t)t * cin_pad + k_off + c] = from_f32<T>(v);
+        else wp[(int64_t)(row_off + c) * ktot + (int64_t)(taps - 1 - t) * cin_pad + k_off + o] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+static int pack_weight_t(int mode, const float* w, int co, int ci, int kh, int kw, void* wp, int rows_pad, int cin_pad,
+                         int row_off, int k_off, hipStream_t s) {
+    dbx_conv_desc d; d.dtype = DType<T>::id; d.kh = kh; d.kw = kw; d.cin_pad = cin_pad; d.cout_pad = rows_pad;
+    const int64_t ktot = packed_k_elems(&d);
+    const int rows = mode == 0 ? co : ci, cols = mode == 0 ? ci : co;
+    DBX_REQUIRE(row_off + rows <= rows_pad && k_off + cols <= cin_pad, "pack_weight: slice out of range");
+    const int64_t total = (int64_t)co * ci * kh * kw;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, s, w, co, ci, kh * kw, mode, (T*)wp, ktot,
+                       cin_pad, row_off, k_off);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+extern "C" int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw, int32_t co, int32_t ci, int32_t kh,
+                               int32_t kw, void* w_packed, int32_t rows_pad, int32_t cin_pad, int32_t row_off,
+                               int32_t k_off, void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, pack_weight_t, mode, w_oihw, co, ci, kh, kw, w_packed, rows_pad, cin_pad, row_off, k_off,
+                       (hipStream_t)stream);
+}

@@ -1,0 +1,308 @@
+"""Host-side execution engine: plans framed-NHWC buffers in one HBM workspace and drives the
+HIP kernels of libdensebox_hip.so for forward / backward of the three DenseBox networks.
+
+torch is used for device memory, streams and autograd bookkeeping only; every FLOP of the
+network runs in the library.  Layer graph = DenseBox.py:180-228 / :412-473 / :674-738.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import View, ConvDesc, check, ptr, stream_ptr
+
+# (param stem, cin, cout) of the executed backbone, in order; pools after conv1_2, conv2_2, (conv3_4 -> pool3)
+_BACKBONE = [('conv1_1_1', 3, 64), ('conv1_2_1', 64, 64), ('conv2_1_1', 64, 128), ('conv2_2_1', 128, 128),
+             ('conv3_1_1', 128, 256), ('conv3_2_1', 256, 256), ('conv3_4_1', 256, 256),
+             ('conv4_1_1', 256, 512), ('conv4_2_1', 512, 512), ('conv4_3_1', 512, 512), ('conv4_4_1', 512, 512)]
+
+# heads in hidden-buffer order: (stem, k)
+_HEADS = {
+    'DenseBox': [('det', 1), ('loc', 4)],
+    'DenseBoxLM': [('det', 1), ('loc', 4), ('landmark', 4)],
+    'DenseBoxLMLOC': [('det', 1), ('loc', 4), ('landmark', 4), ('lmloc', 8)],
+}
+
+
+def _align(x, a=256):
+    return (x + a - 1) // a * a
+
+
+class Buf:
+    """A framed NHWC buffer inside the workspace."""
+
+    def __init__(self, name, n, h, w, c, pad, dtype_id):
+        self.name, self.n, self.h, self.w, self.c, self.pad = name, n, h, w, c, pad
+        self.dtype_id = dtype_id
+        self.es = _lib.ESIZE[dtype_id]
+        self.hp, self.wp = h + 2 * pad, w + 2 * pad
+        self.bytes = n * self.hp * self.wp * c * self.es
+        # guard band: the weight-gradient kernel walks the frame linearly and reads taps up to (wp+1)*kmax pixels
+        # before/after it; keep those reads inside the (zeroed) allocation
+        self.guard = _align((self.wp + 2) * c * self.es * 4)
+        self.base = None     # device address of element (0,-pad,-pad,0)
+
+    def view(self, c_off=0, c=None):
+        return View(C.c_void_p(self.base), self.n, self.h, self.w, self.pad, self.c, c_off,
+                    self.c - c_off if c is None else c)
+
+
+class Plan:
+    """Workspace layout for one (N, H, W, dtype, train) configuration."""
+
+    def __init__(self, kind, n, h, w, dtype_id, device, train):
+        self.kind, self.n, self.h, self.w, self.dtype_id, self.train = kind, n, h, w, dtype_id, train
+        es = _lib.ESIZE[dtype_id]
+        self.cin0 = 16 // es                      # conv1_1 input channels padded to one 16-byte chunk
+        self.crf = 8 if es == 2 else 32           # refine input channels (5) padded: 16 B chunk, or a 128 B K step in f32
+        nh = len(_HEADS[kind])
+        h2, w2, h4, w4, h8, w8 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
+        self.h4, self.w4 = h4, w4
+        B = {}
+
+        def add(name, hh, ww, c, pad=1):
+            B[name] = Buf(name, n, hh, ww, c, pad, dtype_id)
+        add('x0', h, w, self.cin0)
+        add('a11', h, w, 64); add('a12', h, w, 64); add('p1', h2, w2, 64)
+        add('a21', h2, w2, 128); add('a22', h2, w2, 128); add('p2', h4, w4, 128)
+        add('a31', h4, w4, 256); add('a32', h4, w4, 256)
+        add('fusion', h4, w4, 768)                # [0:512) = upsampled conv4_4, [512:768) = conv3_4 (concat for free)
+        add('p3', h8, w8, 256)
+        add('a41', h8, w8, 512); add('a42', h8, w8, 512); add('a43', h8, w8, 512); add('a44', h8, w8, 512)
+        add('hid', h4, w4, 512 * nh, pad=0)
+        if kind != 'DenseBox':
+            add('rf_in', h4, w4, self.crf, pad=0)
+            add('rf_p', h8, w8, self.crf, pad=0)
+            add('rf_1', h8 - 2, w8 - 2, 64, pad=0)
+            add('rf_2', h8 - 6, w8 - 6, 64, pad=0)
+            add('rf_u', h4, w4, 64, pad=0)
+        if train:
+            # gradients (dZ = dL/d pre-activation) live in frames congruent to the matching activation
+            for nm in ('a11', 'a12', 'a21', 'a22', 'a31', 'a32', 'a41', 'a42', 'a43', 'a44'):
+                add('d_' + nm, B[nm].h, B[nm].w, B[nm].c)
+            add('d_c34', h4, w4, 256)
+            add('d_ups', h4, w4, 512, pad=0)
+            add('d_p1', h2, w2, 64, pad=0); add('d_p2', h4, w4, 128, pad=0); add('d_p3', h8, w8, 256, pad=0)
+            add('d_hid', h4, w4, 512 * nh, pad=0)
+            add('d_out', h4, w4, self.crf * nh, pad=0)    # dL/d(head outputs), one crf-channel slot per head
+            if kind != 'DenseBox':
+                add('d_rf_u', h4, w4, 64, pad=0)
+                add('d_rf_2', h8 - 2, w8 - 2, 64, pad=4)     # framed like rf_1 (5x5 dgrad needs a 4-px frame)
+                add('d_rf_1', h8, w8, 64, pad=2)             # framed like rf_p (3x3 dgrad needs a 2-px frame)
+                add('d_rf_p', h8, w8, self.crf, pad=0)
+                add('d_rf_in', h4, w4, self.crf, pad=0)
+        off = 0
+        for b in B.values():
+            off += b.guard
+            b.off = off
+            off += _align(b.bytes) + b.guard
+        self.mask_off = off
+        self.mask_bytes = _align(n * h4 * w4 * 512 * nh) if train else 0
+        off += self.mask_bytes
+        self.total = off
+        self.ws = torch.zeros(off, dtype=torch.uint8, device=device)
+        base = self.ws.data_ptr()
+        assert base % 256 == 0
+        for b in B.values():
+            b.base = base + b.off
+        self.B = B
+        self.mask_ptr = base + self.mask_off
+
+
+class Engine:
+    def __init__(self, net):
+        self.net = net
+        self.kind = net.KIND
+        self.L = _lib.lib()
+        self.plans = {}
+        self.wcache = {}       # (name, mode, dtype) -> (version key, packed tensor)
+        self.bias_cache = {}
+        self.last_plan = None
+
+    # ------------------------------------------------------------------ parameters
+    def _param(self, name):
+        mod, attr = name.rsplit('.', 1)
+        return getattr(getattr(self.net, mod), attr)
+
+    def _packed(self, key, builder, versions):
+        ent = self.wcache.get(key)
+        if ent is not None and ent[0] == versions:
+            return ent[1]
+        t = builder()
+        self.wcache[key] = (versions, t)
+        return t
+
+    def _pack(self, dt, mode, w, rows_pad, cin_pad, kh, kw, out=None, row_off=0, k_off=0):
+        """fp32 OIHW parameter -> packed compute-dtype matrix [rows_pad][ktot]."""
+        d = ConvDesc(dt, kh, kw, 0, cin_pad, rows_pad, 0)
+        elems = self.L.dbx_conv_packed_elems(C.byref(d))
+        if out is None:
+            out = torch.zeros(elems * _lib.ESIZE[dt], dtype=torch.uint8, device=w.device)
+        co, ci = w.shape[0], w.shape[1]
+        check(self.L.dbx_pack_weight(dt, mode, ptr(w.detach()), co, ci, kh, kw, ptr(out), rows_pad, cin_pad,
+                                     row_off, k_off, stream_ptr()))
+        return out
+
+    def _bias(self, names, pad_to):
+        ps = [self._param(n + '.bias') for n in names]
+        key = tuple(names)
+        ver = tuple((p._version, p.data_ptr()) for p in ps)
+        ent = self.bias_cache.get(key)
+        if ent is not None and ent[0] == ver:
+            return ent[1]
+        b = torch.zeros(pad_to, dtype=torch.float32, device=ps[0].device)
+        o = 0
+        for p in ps:
+            b[o:o + p.numel()].copy_(p.detach())
+            o += p.numel()
+        self.bias_cache[key] = (ver, b)
+        return b
+
+    def _w_fwd(self, dt, stem, cin_pad, cout_pad):
+        w = self._param(stem + '.weight')
+        return self._packed((stem, 0, dt), lambda: self._pack(dt, 0, w, cout_pad, cin_pad, w.shape[2], w.shape[3]),
+                            (w._version, w.data_ptr()))
+
+    def _w_heads1(self, dt):
+        heads = _HEADS[self.kind]
+        ws = [self._param('conv5_1_%s.weight' % s) for s, _ in heads]
+
+        def build():
+            out = None
+            for i, w in enumerate(ws):
+                out = self._pack(dt, 0, w, 512 * len(ws), 768, 1, 1, out=out, row_off=512 * i)
+            return out
+        return self._packed(('heads1', 0, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+
+    # ------------------------------------------------------------------ plumbing
+    def plan(self, n, h, w, dt, device, train):
+        key = (n, h, w, dt, train)
+        p = self.plans.get(key)
+        if p is None:
+            p = Plan(self.kind, n, h, w, dt, device, train)
+            self.plans = {key: p}      # keep one plan alive (shape changes re-plan)
+        return p
+
+    def _conv(self, dt, x, y, wpk, bias, kh, kw, cpad, cin_pad, cout_pad, epi, gate=None, dropmask=None, dm_ld=0):
+        d = ConvDesc(dt, kh, kw, cpad, cin_pad, cout_pad, epi)
+        check(self.L.dbx_conv_forward(C.byref(d), C.byref(x), ptr(wpk), ptr(bias), C.byref(y),
+                                      C.byref(gate) if gate is not None else None,
+                                      C.c_void_p(dropmask) if dropmask else None, dm_ld, stream_ptr()))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, X):
+        net = self.net
+        train = net.training and torch.is_grad_enabled()
+        params = [p for _, p in net.named_parameters()]
+        if train and any(p.requires_grad for p in params):
+            from .autograd import NetFunction
+            outs = NetFunction.apply(self, X, *params)
+            names = self.output_names()
+            return dict(zip(names, outs))
+        return self.forward_raw(X, train=net.training)
+
+    def output_names(self):
+        return [s for s, _ in _HEADS[self.kind]] + ([] if self.kind == 'DenseBox' else ['refine'])
+
+    def forward_raw(self, X, train):
+        """Runs the network; returns dict name -> fp32 NCHW tensor.  Activations stay in the plan's workspace."""
+        assert X.dim() == 4 and X.size(1) == 3, 'input must be [N,3,H,W]'
+        L, kind = self.L, self.kind
+        dt = _lib.DTYPE_ID[self.net.compute_dtype]
+        n, _, h, w = X.shape
+        assert h >= 8 and w >= 8, 'input smaller than the /8 stride'
+        if kind != 'DenseBox':
+            assert h // 8 >= 7 and w // 8 >= 7, 'refine branch (3x3 + 5x5 un-padded convs) needs H/8, W/8 >= 7'
+        dev = X.device
+        P = self.plan(n, h, w, dt, dev, train)
+        self.last_plan = P
+        B = P.B
+        s = stream_ptr()
+        Xf = X.detach().to(torch.float32).contiguous()
+        check(L.dbx_nchw_to_framed(dt, ptr(Xf), 3, C.byref(B['x0'].view()), s))
+        RELU = _lib.EPI_BIAS | _lib.EPI_RELU
+
+        def conv3(stem, src, dst, cin, cout, dst_view=None):
+            cin_pad = P.cin0 if cin == 3 else cin
+            wp = self._w_fwd(dt, stem, cin_pad, max(64, cout))
+            self._conv(dt, B[src].view(), dst_view if dst_view is not None else B[dst].view(), wp,
+                       self._bias([stem], max(64, cout)), 3, 3, 1, cin_pad, max(64, cout), RELU)
+
+        conv3('conv1_1_1', 'x0', 'a11', 3, 64)
+        conv3('conv1_2_1', 'a11', 'a12', 64, 64)
+        check(L.dbx_maxpool2x2(dt, C.byref(B['a12'].view()), C.byref(B['p1'].view()), s))
+        conv3('conv2_1_1', 'p1', 'a21', 64, 128)
+        conv3('conv2_2_1', 'a21', 'a22', 128, 128)
+        check(L.dbx_maxpool2x2(dt, C.byref(B['a22'].view()), C.byref(B['p2'].view()), s))
+        conv3('conv3_1_1', 'p2', 'a31', 128, 256)
+        conv3('conv3_2_1', 'a31', 'a32', 256, 256)
+        c34 = B['fusion'].view(512, 256)
+        conv3('conv3_4_1', 'a32', None, 256, 256, dst_view=c34)       # writes fusion[:, 512:768]
+        check(L.dbx_maxpool2x2(dt, C.byref(c34), C.byref(B['p3'].view()), s))
+        conv3('conv4_1_1', 'p3', 'a41', 256, 512)
+        conv3('conv4_2_1', 'a41', 'a42', 512, 512)
+        conv3('conv4_3_1', 'a42', 'a43', 512, 512)
+        conv3('conv4_4_1', 'a43', 'a44', 512, 512)
+        check(L.dbx_upsample_bilinear(dt, C.byref(B['a44'].view()), C.byref(B['fusion'].view(0, 512)), s))
+
+        # heads: one GEMM 768 -> 512*nh over the shared fusion tensor, then 512 -> k per head
+        heads = _HEADS[kind]
+        nh = len(heads)
+        epi = _lib.EPI_BIAS
+        dm = None
+        if train:
+            dm = P.mask_ptr
+            self._fill_dropout(P, heads)
+            epi |= _lib.EPI_DROPMASK
+        self._conv(dt, B['fusion'].view(), B['hid'].view(), self._w_heads1(dt),
+                   self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh), 1, 1, 0, 768, 512 * nh, epi,
+                   dropmask=dm, dm_ld=512 * nh)
+        outs = {}
+        h4, w4 = P.h4, P.w4
+        for i, (stem, k) in enumerate(heads):
+            o = torch.empty((n, k, h4, w4), dtype=torch.float32, device=dev)
+            yv = View(C.c_void_p(o.data_ptr()), n, h4, w4, 0, k, 0, k)
+            self._conv(dt, B['hid'].view(512 * i, 512), yv, self._w_fwd(dt, 'conv5_2_' + stem, 512, 64),
+                       self._bias(['conv5_2_' + stem], 64), 1, 1, 0, 512, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
+            outs[stem] = o
+        if kind != 'DenseBox':
+            # refine branch: cat(landmarks, score) -> pool4 -> 3x3 -> 5x5 -> bilinear -> 1x1   (DenseBox.py:464-471)
+            rin = B['rf_in'].view()
+            check(L.dbx_nchw_to_framed_ch(dt, ptr(outs['landmark']), 4, C.byref(rin), 0, s))
+            check(L.dbx_nchw_to_framed_ch(dt, ptr(outs['det']), 1, C.byref(rin), 4, s))
+            check(L.dbx_maxpool2x2(dt, C.byref(rin), C.byref(B['rf_p'].view()), s))
+            self._conv(dt, B['rf_p'].view(), B['rf_1'].view(), self._w_fwd(dt, 'conv6_1_det', P.crf, 64),
+                       self._bias(['conv6_1_det'], 64), 3, 3, 0, P.crf, 64, _lib.EPI_BIAS)
+            self._conv(dt, B['rf_1'].view(), B['rf_2'].view(), self._w_fwd(dt, 'conv6_2_det', 64, 64),
+                       self._bias(['conv6_2_det'], 64), 5, 5, 0, 64, 64, _lib.EPI_BIAS)
+            check(L.dbx_upsample_bilinear(dt, C.byref(B['rf_2'].view()), C.byref(B['rf_u'].view()), s))
+            o = torch.empty((n, 1, h4, w4), dtype=torch.float32, device=dev)
+            yv = View(C.c_void_p(o.data_ptr()), n, h4, w4, 0, 1, 0, 1)
+            self._conv(dt, B['rf_u'].view(), yv, self._w_fwd(dt, 'conv6_3_det', 64, 64),
+                       self._bias(['conv6_3_det'], 64), 1, 1, 0, 64, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
+            outs['refine'] = o
+        return outs
+
+    def _fill_dropout(self, P, heads):
+        """Training-mode keep-masks: injected (parity) or drawn by the device RNG."""
+        nh = len(heads)
+        inj = self.net.dropout_masks
+        nbytes = P.n * P.h4 * P.w4 * 512 * nh
+        if inj is not None:
+            # injected masks arrive as {head: uint8/bool/float [N,512,h,w]} (NCHW like the reference's Dropout input)
+            m = torch.empty((P.n, P.h4, P.w4, nh, 512), dtype=torch.uint8, device=P.ws.device)
+            for i, (stem, _) in enumerate(heads):
+                m[:, :, :, i, :] = inj[stem].to(P.ws.device).permute(0, 2, 3, 1).to(torch.uint8)
+            P.ws[P.mask_off:P.mask_off + nbytes].copy_(m.reshape(-1))
+        else:
+            self._seed = getattr(self, '_seed', 0x5eed) + 1
+            check(self.L.dbx_dropout_mask(C.c_void_p(P.mask_ptr), _align(nbytes, 16), self._seed, stream_ptr()))
+
+    # debugging / tests: read an activation back as fp32 NCHW
+    def read_activation(self, name, c_off=0, c=None):
+        P = self.last_plan
+        b = P.B[name]
+        v = b.view(c_off, c)
+        out = torch.empty((b.n, v.c, b.h, b.w), dtype=torch.float32, device=P.ws.device)
+        check(self.L.dbx_framed_to_nchw_f32(P.dtype_id, C.byref(v), ptr(out), stream_ptr()))
+        return out

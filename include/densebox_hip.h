@@ -1,0 +1,182 @@
+/*
+ * densebox_hip.h -- C ABI of libdensebox_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (CaptainEven/DenseBox) has NO native/FFI interface: its only
+ * boundary is the Python surface of DenseBox.py.  This header is
+ * therefore the boundary the build defines for the hot path; each entry point
+ * names the reference lines whose arithmetic it replaces.  The Python front end
+ * (densebox_amd/) binds these with ctypes.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative dbx_status otherwise, and
+ *    never throws across the ABI; dbx_last_error() gives a thread-local message.
+ *  - all pointers are DEVICE pointers owned by the caller (torch allocates);
+ *    the library owns nothing, keeps no state between calls, and is re-entrant.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *    every call is asynchronous with respect to the host.
+ *  - activations are "framed NHWC": [N][H+2p][W+2p][ld] elements of the compute
+ *    dtype, the p-pixel frame is zero and is never written by any kernel.
+ */
+#ifndef DENSEBOX_HIP_H
+#define DENSEBOX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum dbx_status {
+    DBX_OK = 0,
+    DBX_ERR_ARG = -1,      /* bad descriptor / unsupported shape */
+    DBX_ERR_HIP = -2,      /* a HIP runtime call failed (launch, memset) */
+    DBX_ERR_DTYPE = -3
+};
+
+enum dbx_dtype { DBX_F16 = 0, DBX_BF16 = 1, DBX_F32 = 2 };
+
+const char* dbx_last_error(void);
+int dbx_version(void);
+/* device sanity: returns gfx arch number (950) of `device`, or <0 */
+int dbx_device_arch(int device);
+
+/* ------------------------------------------------------------------ framed NHWC tensor view */
+typedef struct dbx_view {
+    void*   ptr;      /* element (n=0, y=-pad, x=-pad, c=0) of the frame */
+    int32_t n, h, w;  /* logical (unframed) extent */
+    int32_t pad;      /* frame width in pixels (0, 1, or kh-1 for the un-padded refine convs' gradients) */
+    int32_t ld;       /* elements per pixel (>= c_off + c) */
+    int32_t c_off;    /* first channel this view addresses */
+    int32_t c;        /* channels in this view */
+} dbx_view;
+
+/* ------------------------------------------------------------------ convolution (implicit GEMM on MFMA)
+ * y[n,oy,ox,co] = epi( sum_{ky,kx,ci} x[n, oy+ky-cpad, ox+kx-cpad, ci] * w[co][ky][kx][ci] + bias[co] )
+ * Replaces nn.Conv2d(+ReLU) at DenseBox.py:185-209 (3x3 backbone), :223-224/:455-461/:717-726
+ * (1x1 heads), :466-471 (refine branch), and -- with transposed/flipped packed weights --
+ * autograd's dgrad of the same layers (DenseBox.py:2186 loss.backward()).
+ */
+enum dbx_epilogue {
+    DBX_EPI_BIAS     = 1,   /* + bias[co] (fp32) */
+    DBX_EPI_RELU     = 2,   /* max(.,0) */
+    DBX_EPI_GATE     = 4,   /* zero where gate[n,oy,ox,co] <= 0 (ReLU backward; gate = forward activation) */
+    DBX_EPI_DROPMASK = 8,   /* * 2 * mask[m][co] (uint8 {0,1}, unframed [M][c]) -- nn.Dropout(0.5) train mode */
+    DBX_EPI_ACCUM    = 16,  /* y += result (dtype of y) */
+    DBX_EPI_F32_NCHW = 32   /* write fp32 NCHW [N][cv][Ho][Wo] (cv = y->c valid channels) instead of framed NHWC */
+};
+
+typedef struct dbx_conv_desc {
+    int32_t dtype;         /* dbx_dtype of x, w and (unless F32_NCHW) y */
+    int32_t kh, kw;        /* 1x1, 3x3, 5x5 */
+    int32_t cpad;          /* conv padding (0 or 1); x->pad >= cpad */
+    int32_t cin_pad;       /* channels per tap in the packed weight (multiple of 16 bytes worth) */
+    int32_t cout_pad;      /* rows of the packed weight (multiple of 64) */
+    int32_t epilogue;      /* OR of dbx_epilogue */
+} dbx_conv_desc;
+
+/* packed weight: [cout_pad][ktot] elements, ktot = roundup(kh*kw*cin_pad*esize, 128 B)/esize, k = tap*cin_pad + ci */
+int64_t dbx_conv_packed_elems(const dbx_conv_desc* d);
+int dbx_conv_forward(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
+                     const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int32_t dropmask_ld,
+                     void* stream);
+
+/* fp32 OIHW [co][ci][kh][kw] -> packed compute-dtype weight.
+ * mode 0: forward            wp[co][tap][ci]            = w[co][ci][tap]
+ * mode 1: dgrad (transposed) wp[ci][taps-1-tap][co]     = w[co][ci][tap]   (rows = ci, "cin" = co)
+ * ci_off/ci_cnt select an input-channel slice (used to concatenate several heads' 1x1 weights). */
+int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw, int32_t co, int32_t ci, int32_t kh, int32_t kw,
+                    void* w_packed, int32_t rows_pad, int32_t cin_pad, int32_t row_off, int32_t k_off, void* stream);
+
+/* ------------------------------------------------------------------ weight gradient
+ * dw[co][ci][ky][kx] (+)= sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-cpad,x+kx-cpad,ci]   (fp32 OIHW, DenseBox.py:2186)
+ * db[co] = sum dz.   dz and x must live in frames of identical geometry (same n,h,w,pad).
+ * `partial` is a scratch buffer of dbx_conv_wgrad_scratch_bytes(); the reduction over it is deterministic.
+ */
+int64_t dbx_conv_wgrad_scratch_bytes(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw);
+int dbx_conv_wgrad(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, int32_t cpad,
+                   float* dw_oihw, float* db, void* partial, void* stream);
+
+/* ------------------------------------------------------------------ layout / pooling / resampling
+ * nchw_to_framed: network input X (DenseBox.py:185) fp32 NCHW -> framed NHWC compute dtype (channels padded with 0).
+ * maxpool2x2:     nn.MaxPool2d(2,2) floor mode (DenseBox.py:187,191,204,465), first-max-wins like ATen.
+ * maxpool2x2_bwd: gradient routed to the arg-max, times ReLU gate of the pre-pool activation.
+ * upsample:       nn.Upsample(size, bilinear, align_corners=True) (DenseBox.py:213-216, :468-470).
+ */
+/* x_nchw has c_src channels; channels c_src..y->c-1 of the framed view are written as 0 (also used for dL/dout) */
+int dbx_nchw_to_framed(int32_t dtype, const float* x_nchw, int32_t c_src, const dbx_view* y, void* stream);
+/* scatter c_src fp32 NCHW planes into channels [c_dst_off, c_dst_off+c_src) of y; other channels untouched
+ * (builds cat(landmarks, score), DenseBox.py:464 / :729) */
+int dbx_nchw_to_framed_ch(int32_t dtype, const float* x_nchw, int32_t c_src, const dbx_view* y, int32_t c_dst_off,
+                          void* stream);
+int dbx_framed_to_nchw_f32(int32_t dtype, const dbx_view* x, float* y_nchw, void* stream);
+/* nn.Dropout(p=0.5) keep-mask bytes {0,1} from a counter-based device RNG (DenseBox.py:160); nbytes % 16 == 0 */
+int dbx_dropout_mask(uint8_t* mask, int64_t nbytes, uint64_t seed, void* stream);
+int dbx_maxpool2x2(int32_t dtype, const dbx_view* x, const dbx_view* y, void* stream);
+/* x = pre-pool activation, dy = grad of the pooled map, dx = grad of the pre-pool map (same frame as x) */
+int dbx_maxpool2x2_bwd(int32_t dtype, const dbx_view* x, const dbx_view* dy, const dbx_view* dx,
+                       int32_t accumulate, int32_t relu_gate, void* stream);
+int dbx_upsample_bilinear(int32_t dtype, const dbx_view* x, const dbx_view* y, void* stream);
+/* gate (optional): forward activation of dx's tensor; dx is zeroed where gate <= 0 (ReLU backward) */
+int dbx_upsample_bilinear_bwd(int32_t dtype, const dbx_view* dy, const dbx_view* dx, const dbx_view* gate, void* stream);
+
+/* ------------------------------------------------------------------ dense per-pixel loss (DenseBox.py:2023-2180 etc.)
+ * One call builds the label maps (a5-a8), element-wise L2, hard-negative mining (top-k per sample),
+ * mask fill + gray zones (a11-a13), the weighted sums (a14/a15) and dL/d(out) for every head.
+ */
+typedef struct dbx_loss_desc {
+    int32_t kind;            /* 0 DenseBox (train_online), 1 DenseBoxLM (train_LM_online), 2 DenseBoxLMLOC (train_densebox_online) */
+    int32_t n;               /* local batch */
+    int32_t half_neg;        /* hard negatives per sample = random negatives per sample (DenseBox.py:2081) */
+    float   lambda_loc, lambda_det, lambda_lm;
+    int32_t use_labels;      /* _pn variants: skip label==0 patches (kind 2) */
+} dbx_loss_desc;
+
+typedef struct dbx_loss_io {
+    const float* bbox;       /* [n,4] 60-space corners */
+    const float* vertices;   /* [n,8] or NULL */
+    const float* labels;     /* [n,1] or NULL */
+    const int64_t* rand_neg; /* [n,half_neg] */
+    const int64_t* lm_rand_neg; /* [4,n,1] or NULL */
+    const float* score;  const float* loc;  const float* lm;  const float* rf;  const float* lmloc;   /* fp32 NCHW outputs */
+    float* d_score; float* d_loc; float* d_lm; float* d_rf; float* d_lmloc;                           /* fp32 NCHW grads (may be NULL) */
+    float* loss;             /* [1] */
+    float* mask_cls;         /* [n,1,60,60] out (debug/parity) or NULL */
+    float* mask_lm;          /* [n,4,60,60] out or NULL */
+    int64_t* neg_idx;        /* [n,2*half_neg] out or NULL */
+    int64_t* lm_neg_idx;     /* [4,n,2] out or NULL */
+    int32_t* pos_count;      /* [n] positives per sample out or NULL */
+} dbx_loss_io;
+
+int dbx_loss_forward_backward(const dbx_loss_desc* d, const dbx_loss_io* io, void* stream);
+/* positives per sample from the boxes alone (a5) -- lets the host derive half_neg without reading maps back */
+int dbx_count_positives(const float* bbox, const float* labels, int32_t n, int32_t* count_per_sample, void* stream);
+
+/* label-map generators as stand-alone ops (reference function names in DenseBox.py:1556-1914) */
+int dbx_init_score_map(const float* bbox, const float* labels, int32_t n, float* out, void* stream);
+int dbx_init_offset_map(const float* coords, const float* labels, int32_t n, int32_t c, float* out, void* stream);
+int dbx_init_lm_heatmap(const float* vertices, const float* labels, int32_t n, int32_t clamp, float* out, void* stream);
+int dbx_mask_by_sel(float* mask, int32_t n, const int64_t* pos_idx, int64_t n_pos, const int64_t* neg_idx, int32_t n_neg, void* stream);
+int dbx_mask_gray_zone_cls(float* mask, const float* bbox, const float* labels, int32_t n, void* stream);
+int dbx_mask_gray_zone_lm(float* mask, int32_t n, const int64_t* pos_idx, int64_t n_pos, void* stream);
+
+/* ------------------------------------------------------------------ SGD (DenseBox.py:2001-2004, torch semantics)
+ * for each tensor t: g = grad + wd*p; buf = first ? g : mu*buf + g; p -= lr*buf
+ * ptrs: device array of 3*count pointers {p, grad, buf}; sizes: device array of count element counts.
+ */
+int dbx_sgd_step(float* const* ptrs, const int64_t* sizes, int32_t count, int64_t max_size,
+                 float lr, float momentum, float weight_decay, int32_t first_step, void* stream);
+
+/* ------------------------------------------------------------------ decode + NMS (DenseBox.py:3114-3443)
+ * top-K of the score map, corner/landmark decode to float64 rows [K, 5|13], greedy NMS (keep ovr <= thresh).
+ * keep[0] = count, keep[1..] = kept row indices in reference order.
+ */
+int dbx_detect(const float* score, const float* loc, const float* lm_heat, const float* lm_loc,
+               int32_t rows, int32_t cols, int32_t K, double nms_thresh,
+               double* dets, int32_t det_cols, int64_t* topk_idx, int32_t* keep, void* scratch, void* stream);
+int64_t dbx_detect_scratch_bytes(int32_t rows, int32_t cols, int32_t K);
+int dbx_nms(const double* dets, int32_t n, int32_t det_cols, double nms_thresh, int32_t* keep, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DENSEBOX_HIP_H */

@@ -1,0 +1,98 @@
+"""GPU parity: HIP forward (through the C ABI) vs the CPU oracle and the reference-captured fixtures.
+
+Tolerances (outputs are O(1); loc-type outputs O(10)):
+  f32  : |err| <= 1e-4 * max(1, |ref|)   exact-fp32 MFMA, only summation order differs
+  f16  : |err| <= 1e-3 * scale + fp16 activation rounding accumulated over 13 layers -> checked as 4e-3 * max|ref|
+  bf16 : 8x coarser mantissa -> 3e-2 * max|ref|
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import unpack
+from densebox_amd import synth
+import densebox_amd as D
+
+pytestmark = pytest.mark.gpu
+
+KINDS = ['DenseBox', 'DenseBoxLM', 'DenseBoxLMLOC']
+TOL = {'f32': 1e-4, 'f16': 4e-3, 'bf16': 3e-2}
+
+
+def _net(kind, dtype, seed=11):
+    net = getattr(D, kind)(synth.vgg19_standin(seed=0))
+    synth.fill_params_(net, seed)
+    net = net.cuda().eval()
+    net.compute_dtype = dtype
+    return net
+
+
+def _close(a, ref, tol, what):
+    a = a.detach().float().cpu().numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(a - ref).max())
+    assert a.shape == ref.shape, (what, a.shape, ref.shape)
+    assert err <= tol * scale, '%s: max err %.3e > %.1e * %.2f' % (what, err, tol, scale)
+    return err
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f16', 'bf16'])
+@pytest.mark.parametrize('kind', KINDS)
+def test_forward_vs_reference_fixture(golden, kind, dtype):
+    g = golden('net_' + kind)
+    net = _net(kind, dtype, int(g['param_seed']))
+    with torch.no_grad():
+        outs = net(synth.synth_images(2, 240, 240, seed=3).cuda())
+    assert len(outs) == sum(1 for k in g.files if k.startswith('out240_'))
+    for i, o in enumerate(outs):
+        assert o.dtype == torch.float32 and o.is_contiguous()
+        _close(o, g['out240_%d' % i], TOL[dtype], '%s/%s out %d' % (kind, dtype, i))
+    # intermediate taps (first conv + first pool) pin the layer kernels individually
+    eng = net.engine()
+    a11 = eng.read_activation('a11')[0, ::8, ::6, ::6]
+    _close(a11, g['tap_conv1_1_sub'], TOL[dtype], 'conv1_1 tap')
+    p1 = eng.read_activation('p1')[0, ::8, ::4, ::4]
+    _close(p1, g['tap_pool1_sub'], TOL[dtype], 'pool1 tap')
+
+
+@pytest.mark.parametrize('kind', KINDS)
+def test_forward_odd_size(golden, kind):
+    """100x132 input: floor pooling (25x33 maps), upsample target = conv3_4's size (DenseBox.py:213-216)."""
+    g = golden('net_' + kind)
+    net = _net(kind, 'f32', int(g['param_seed']))
+    with torch.no_grad():
+        outs = net(synth.synth_images(1, 100, 132, seed=4).cuda())
+    for i, o in enumerate(outs):
+        _close(o, g['outodd_%d' % i], TOL['f32'], '%s odd out %d' % (kind, i))
+
+
+def test_forward_dropout_injected(golden):
+    """Train-mode forward with the reference's recorded Dropout masks (fixture train_DenseBox_dropout)."""
+    g = golden('train_DenseBox_dropout')
+    net = _net('DenseBox', 'f32', int(g['param_seed']))
+    net.train()
+    n = int(g['batch'])
+    net.dropout_masks = {h: torch.from_numpy(unpack(g['dropmask_%d' % i], (n, 512, 60, 60)))
+                         for i, h in enumerate(['det', 'loc'])}
+    x, _, _, _ = synth.synth_batch(int(g['n_patch']), seed=int(g['seed']))
+    with torch.no_grad():
+        outs = net(x[:n].cuda())
+    for i, o in enumerate(outs):
+        _close(o, g['s0_out_%d' % i], TOL['f32'], 'dropout out %d' % i)
+
+
+def test_forward_cpu_tensor_raises():
+    net = getattr(D, 'DenseBox')(synth.vgg19_standin(seed=0))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 3, 240, 240))
+
+
+def test_whole_image_1080p(golden):
+    """Config 5: whole-image FCN forward at 1080x1920 (maps 270x480), f16."""
+    g = golden('net_DenseBox_1080p')
+    net = _net('DenseBox', 'f16', 11)
+    with torch.no_grad():
+        s, l = net(synth.synth_images(1, 1080, 1920, seed=5).cuda())
+    assert tuple(s.shape) == tuple(g['score_shape'])
+    _close(s[0, 0, ::9, ::8], g['score_sub'], TOL['f16'], '1080p score')
+    _close(l[0, :, ::9, ::8], g['loc_sub'], TOL['f16'], '1080p loc')
