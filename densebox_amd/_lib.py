@@ -53,16 +53,17 @@ SIGNATURES = {
     'dbx_conv_forward': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _VP, _I32, _VP]),
     'dbx_pack_weight': (C.c_int, [_I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
     'dbx_conv_wgrad_scratch_bytes': (_I64, [_I32, _PV, _PV, _I32, _I32]),
-    'dbx_conv_wgrad': (C.c_int, [_I32, _PV, _PV, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),
+    'dbx_conv_wgrad': (C.c_int, [_I32, _PV, _PV, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _VP]),
     'dbx_nchw_to_framed': (C.c_int, [_I32, _VP, _I32, _PV, _VP]),
     'dbx_nchw_to_framed_ch': (C.c_int, [_I32, _VP, _I32, _PV, _I32, _VP]),
     'dbx_framed_to_nchw_f32': (C.c_int, [_I32, _PV, _VP, _VP]),
+    'dbx_framed_add_ch': (C.c_int, [_I32, _PV, _I32, _I32, _PV, _I32, _VP]),
     'dbx_maxpool2x2': (C.c_int, [_I32, _PV, _PV, _VP]),
     'dbx_maxpool2x2_bwd': (C.c_int, [_I32, _PV, _PV, _PV, _I32, _I32, _VP]),
     'dbx_upsample_bilinear': (C.c_int, [_I32, _PV, _PV, _VP]),
     'dbx_upsample_bilinear_bwd': (C.c_int, [_I32, _PV, _PV, _PV, _VP]),
     'dbx_dropout_mask': (C.c_int, [_VP, _I64, C.c_uint64, _VP]),
-    'dbx_loss_forward_backward': (C.c_int, [C.POINTER(LossDesc), C.POINTER(LossIO), _VP]),
+    'dbx_loss_forward_backward': (C.c_int, [C.POINTER(LossDesc), C.POINTER(LossIO), _VP, _VP]),
     'dbx_count_positives': (C.c_int, [_VP, _VP, _I32, _VP, _VP]),
     'dbx_init_score_map': (C.c_int, [_VP, _VP, _I32, _VP, _VP]),
     'dbx_init_offset_map': (C.c_int, [_VP, _VP, _I32, _I32, _VP, _VP]),
@@ -73,7 +74,7 @@ SIGNATURES = {
     'dbx_sgd_step': (C.c_int, [_VP, _VP, _I32, _I64, _F, _F, _F, _I32, _VP]),
     'dbx_detect_scratch_bytes': (_I64, [_I32, _I32, _I32]),
     'dbx_detect': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _D, _VP, _I32, _VP, _VP, _VP, _VP]),
-    'dbx_nms': (C.c_int, [_VP, _I32, _I32, _D, _VP, _VP]),
+    'dbx_nms': (C.c_int, [_VP, _I32, _I32, _D, _VP, _VP, _VP]),
 }
 
 _lib = None

@@ -367,3 +367,33 @@ extern "C" int dbx_dropout_mask(uint8_t* mask, int64_t nbytes, uint64_t seed, vo
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- channel-slice accumulate
+// dst[n,y,x, c_dst_off + j] += src[n,y,x, c_src_off + j], j < n_ch.  Routes the refine branch's input gradient
+// (d cat(landmarks, score), DenseBox.py:464) back onto the landmark / score head gradients.
+template <typename T>
+__global__ void framed_add_ch_kernel(FrameGeo src, int c_src_off, int n_ch, FrameGeo dst, int c_dst_off) {
+    const int64_t total = (int64_t)src.n * src.h * src.w * n_ch;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % n_ch);
+        const int px = (int)((i / n_ch) % src.w);
+        const int py = (int)((i / ((int64_t)n_ch * src.w)) % src.h);
+        const int n = (int)(i / ((int64_t)n_ch * src.w * src.h));
+        T* d = (T*)dst.base + geo_pix(dst, n, py, px) + c_dst_off + j;
+        *d = from_f32<T>(to_f32(*d) + to_f32(((const T*)src.base)[geo_pix(src, n, py, px) + c_src_off + j]));
+    }
+}
+template <typename T>
+static int framed_add_ch_t(const dbx_view* src, int c_src_off, int n_ch, const dbx_view* dst, int c_dst_off, hipStream_t s) {
+    DBX_REQUIRE(src->n == dst->n && src->h == dst->h && src->w == dst->w, "framed_add_ch: shape mismatch");
+    DBX_REQUIRE(c_src_off + n_ch <= src->c && c_dst_off + n_ch <= dst->c, "framed_add_ch: slice out of range");
+    const int64_t total = (int64_t)src->n * src->h * src->w * n_ch;
+    hipLaunchKernelGGL(framed_add_ch_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, make_geo<T>(src), c_src_off, n_ch,
+                       make_geo<T>(dst), c_dst_off);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_framed_add_ch(int32_t dtype, const dbx_view* src, int32_t c_src_off, int32_t n_ch, const dbx_view* dst,
+                                 int32_t c_dst_off, void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, framed_add_ch_t, src, c_src_off, n_ch, dst, c_dst_off, (hipStream_t)stream);
+}

@@ -1,0 +1,302 @@
+// Convolution weight gradient on MFMA for gfx950.
+//
+//   dW[co][tap][ci] = sum_q dz[q][co] * x[q + shift(tap)][ci]          q = linear index over the WHOLE frame
+//
+// dz and x live in frames of identical geometry (N x Hp x Wp pixels); the frame of dz is zero, so walking the
+// frame linearly needs no 2-D index math at all: every tap is the same GEMM against x shifted by a constant
+// number of pixels ("im2col-free" in the literal sense).  The reduction dimension K' = q is the slow (row) index
+// of both operands in memory, so the MFMA fragments need a transpose: f16/bf16 tiles are staged [32 q][channels]
+// in LDS exactly as they sit in HBM and read with ds_read_b64_tr_b16 (each lane receives 4 consecutive q of its
+// channel); f32 uses v_mfma_f32_16x16x4_f32 whose operands are one element per lane (plain ds_read_b32).
+//
+// Grid: (co-tile, ci-tile, tap) x split-K.  Each workgroup writes an fp32 partial slab; a second kernel reduces the
+// slabs in fixed order (deterministic) and scatters into the fp32 OIHW gradient.  Workgroups of ci-tile 0 / tap 0
+// also accumulate the bias gradient db[co] = sum_q dz[q][co] from the tiles they stream anyway.
+#include "common.hpp"
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+struct WgradArgs {
+    const char* dz; const char* x;      // pointing at frame origin, channel c_off
+    float* partial;                     // [splits][co_pad][taps][ci_pad]
+    float* bpartial;                    // [splits][co_pad]
+    long long Q;                        // frame pixels N*Hp*Wp
+    int dz_ld, x_ld;                    // elements per pixel
+    int dz_c, x_c;                      // valid channels in the views
+    int co_pad, ci_pad;                 // padded to tile multiples
+    int taps, kw, wp;                   // taps = kh*kw, frame width
+    int shift0;                         // (pad_x - pad_dz - cpad) applied to both ky and kx
+    int tiles_co, tiles_ci;
+    int rows_per_split;                 // multiple of 32
+};
+
+template <int W> __device__ __forceinline__ int swz16(int r, int b) {   // 2-byte tiles, W channels per row
+    if (W == 128) return r * 256 + (b ^ (((r & 3) << 5) | (((r >> 3) & 1) << 7)));
+    else return r * 128 + (b ^ ((((r >> 1) & 1) << 5) | (((r >> 3) & 1) << 6)));
+}
+
+template <typename T, int BMC, int BNC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    constexpr int ES = sizeof(T);
+    constexpr int WTM = BMC / 2, WTN = BNC / 2;             // 2x2 waves over (co, ci)
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int CPR_A = BMC * ES / 16, CPR_B = BNC * ES / 16;   // 16-byte chunks per tile row
+    constexpr int LD_A = 32 * CPR_A / 256, LD_B = 32 * CPR_B / 256;  // chunks per thread per step
+    constexpr int RSTEP_A = 256 / CPR_A, RSTEP_B = 256 / CPR_B;
+    constexpr int A_BYTES = 32 * BMC * ES, B_BYTES = 32 * BNC * ES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+    char* As = smem;
+    char* Bs = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int t = blockIdx.x;
+    const int tile_ci = t % a.tiles_ci; t /= a.tiles_ci;
+    const int tile_co = t % a.tiles_co; t /= a.tiles_co;
+    const int tap = t;
+    const int split = blockIdx.y;
+    const int ky = tap / a.kw, kx = tap - ky * a.kw;
+    const long long shift = (long long)(ky + a.shift0) * a.wp + (kx + a.shift0);
+    const long long q0 = (long long)split * a.rows_per_split;
+    long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
+    const int nsteps = q1 > q0 ? (int)((q1 - q0 + 31) / 32) : 0;
+    const bool do_bias = (tile_ci == 0 && tap == 0 && a.bpartial != nullptr);
+
+    // ---- loaders
+    const int ca = tid % CPR_A, ra = tid / CPR_A, cb = tid % CPR_B, rb = tid / CPR_B;
+    const bool a_ok = (tile_co * BMC * ES + ca * 16) < a.dz_c * ES;      // chunk inside the view's channels
+    const bool b_ok = (tile_ci * BNC * ES + cb * 16) < a.x_c * ES;
+    const char* ap = a.dz + ((q0 + ra) * a.dz_ld + tile_co * BMC) * (long long)ES + ca * 16;
+    const char* bp = a.x + ((q0 + shift + rb) * a.x_ld + tile_ci * BNC) * (long long)ES + cb * 16;
+    const long long a_row = (long long)a.dz_ld * ES, b_row = (long long)a.x_ld * ES;
+    u32x4 areg[LD_A], breg[LD_B];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto gload = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < LD_A; ++i) areg[i] = a_ok ? *(const u32x4*)(ap + (s * 32LL + i * RSTEP_A) * a_row) : zero4;
+#pragma unroll
+        for (int i = 0; i < LD_B; ++i) breg[i] = b_ok ? *(const u32x4*)(bp + (s * 32LL + i * RSTEP_B) * b_row) : zero4;
+    };
+    auto lds_off_a = [&](int r, int b) { if constexpr (ES == 2) return swz16<BMC>(r, b); else return r * BMC * 4 + b; };
+    auto lds_off_b = [&](int r, int b) { if constexpr (ES == 2) return swz16<BNC>(r, b); else return r * BNC * 4 + b; };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LD_A; ++i) *(u32x4*)(As + buf * A_BYTES + lds_off_a(ra + i * RSTEP_A, ca * 16)) = areg[i];
+#pragma unroll
+        for (int i = 0; i < LD_B; ++i) *(u32x4*)(Bs + buf * B_BYTES + lds_off_b(rb + i * RSTEP_B, cb * 16)) = breg[i];
+    };
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[16 / ES];
+#pragma unroll
+    for (int j = 0; j < 16 / ES; ++j) bsum[j] = 0.f;
+    auto bias_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < LD_A; ++i) {
+            const T* e = (const T*)&areg[i];
+#pragma unroll
+            for (int j = 0; j < 16 / ES; ++j) bsum[j] += to_f32(e[j]);
+        }
+    };
+
+    if (nsteps > 0) {
+        gload(0);
+        if (do_bias) bias_acc();
+        lstore(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        const char* Ab = As + buf * A_BYTES;
+        const char* Bb = Bs + buf * B_BYTES;
+        if constexpr (ES == 2) {
+            // lane l of 16-lane group g: tr-read of the 4x16 block [q = 8g+4h .. +3][c0 .. c0+15] delivers, to lane i,
+            // the 4 consecutive q of channel c0+i: out[i][j] = in[lane 4j + (i>>2)][i&3]
+            const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
+            u32x4 af[MI], bf[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int cbyte = (wm * WTM + mi * 16) * 2 + csub;
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(Ab + swz16<BMC>(8 * g + rsub, cbyte)));
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(Ab + swz16<BMC>(8 * g + 4 + rsub, cbyte)));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                af[mi] = (u32x4){l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int cbyte = (wn * WTN + ni * 16) * 2 + csub;
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(Bb + swz16<BNC>(8 * g + rsub, cbyte)));
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) short4v*)(Bb + swz16<BNC>(8 * g + 4 + rsub, cbyte)));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                bf[ni] = (u32x4){l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    if constexpr (sizeof(T) == 2 && DType<T>::id == DBX_F16)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mi]),
+                                                                             __builtin_bit_cast(f16x8, bf[ni]), acc[mi][ni], 0, 0, 0);
+                    else
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]),
+                                                                              __builtin_bit_cast(bf16x8, bf[ni]), acc[mi][ni], 0, 0, 0);
+                }
+        } else {
+            // f32: A[i][k=g] = dz[q=4kk+g][co0+i], B[k=g][j] = x[q=4kk+g][ci0+j]
+            const int g = lane >> 4, i16 = lane & 15;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                float af[MI], bf[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) af[mi] = *(const float*)(Ab + ((4 * kk + g) * BMC + wm * WTM + mi * 16 + i16) * 4);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bf[ni] = *(const float*)(Bb + ((4 * kk + g) * BNC + wn * WTN + ni * 16 + i16) * 4);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        if (s + 1 < nsteps) {
+            if (do_bias) bias_acc();
+            lstore(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- partial slab: [split][co][tap][ci]; lane holds co = (l>>4)*4 + r, ci = l&15 of each fragment
+    {
+        float* P = a.partial + (((long long)split * a.co_pad) * a.taps) * a.ci_pad;
+        const int co_b = tile_co * BMC + wm * WTM + (lane >> 4) * 4;
+        const int ci_b = tile_ci * BNC + wn * WTN + (lane & 15);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const float v[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    P[((long long)(co_b + mi * 16 + r) * a.taps + tap) * a.ci_pad + ci_b + ni * 16] = v[r];
+            }
+    }
+    if (do_bias) {
+        // reduce the per-thread column sums over the row groups (threads with equal chunk column ca)
+        __syncthreads();
+        float* red = (float*)smem;                       // [RSTEP_A][BMC]
+#pragma unroll
+        for (int j = 0; j < 16 / ES; ++j) red[ra * BMC + ca * (16 / ES) + j] = bsum[j];
+        __syncthreads();
+        if (tid < BMC) {
+            float s = 0.f;
+            for (int r = 0; r < RSTEP_A; ++r) s += red[r * BMC + tid];
+            a.bpartial[(long long)split * a.co_pad + tile_co * BMC + tid] = s;
+        }
+    }
+}
+
+// dw[co][ci][tap] = sum_s partial[s][co][tap][ci]   (fixed summation order), db[co] = sum_s bpartial[s][co]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits, int co,
+                                    int ci, int taps, int co_pad, int ci_pad, float* __restrict__ dw, float* __restrict__ db,
+                                    int accumulate) {
+    const long long total = (long long)co * taps * ci;
+    const long long slab = (long long)co_pad * taps * ci_pad;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total + co; i += (long long)gridDim.x * blockDim.x) {
+        if (i < total) {
+            const int c = (int)(i % ci);
+            const int t = (int)((i / ci) % taps);
+            const int o = (int)(i / ((long long)ci * taps));
+            const long long src = ((long long)o * taps + t) * ci_pad + c;
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += partial[k * slab + src];
+            const long long dst = ((long long)o * ci + c) * taps + t;
+            dw[dst] = accumulate ? dw[dst] + s : s;
+        } else if (db) {
+            const int o = (int)(i - total);
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += bpartial[(long long)k * co_pad + o];
+            db[o] = accumulate ? db[o] + s : s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split; long long Q; };
+
+static WgradPlan wgrad_plan(const dbx_view* dz, const dbx_view* x, int kh, int kw) {
+    WgradPlan p;
+    p.bmc = dz->c > 64 ? 128 : 64;
+    p.bnc = x->c > 64 ? 128 : 64;
+    if (p.bmc != p.bnc) { p.bmc = 64; p.bnc = 64; }        // compiled tile shapes: 128x128 and 64x64
+    p.co_pad = (dz->c + p.bmc - 1) / p.bmc * p.bmc;
+    p.ci_pad = (x->c + p.bnc - 1) / p.bnc * p.bnc;
+    p.tiles_co = p.co_pad / p.bmc; p.tiles_ci = p.ci_pad / p.bnc;
+    p.taps = kh * kw;
+    p.Q = (long long)dz->n * (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad);
+    const long long tiles = (long long)p.tiles_co * p.tiles_ci * p.taps;
+    const long long steps = (p.Q + 31) / 32;
+    long long splits = (1024 + tiles - 1) / tiles;            // aim for ~4 workgroups per CU
+    const long long max_by_steps = steps / 16 > 0 ? steps / 16 : 1;   // at least 16 K-steps (512 rows) per split
+    if (splits > max_by_steps) splits = max_by_steps;
+    if (splits > 256) splits = 256;
+    if (splits < 1) splits = 1;
+    long long sps = (steps + splits - 1) / splits;
+    p.rows_per_split = (int)(sps * 32);
+    p.splits = (int)((p.Q + p.rows_per_split - 1) / p.rows_per_split);
+    return p;
+}
+
+extern "C" int64_t dbx_conv_wgrad_scratch_bytes(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw) {
+    (void)dtype;
+    const WgradPlan p = wgrad_plan(dz, x, kh, kw);
+    return ((int64_t)p.splits * p.co_pad * p.taps * p.ci_pad + (int64_t)p.splits * p.co_pad) * 4 + 256;
+}
+
+template <typename T>
+static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cpad, int co, int ci, float* dw, float* db,
+                   void* scratch, int accumulate, hipStream_t s) {
+    constexpr int ES = sizeof(T);
+    DBX_REQUIRE(dz->n == x->n && dz->h + 2 * dz->pad == x->h + 2 * x->pad && dz->w + 2 * dz->pad == x->w + 2 * x->pad,
+                "wgrad: dz frame %dx%d(+%d) and x frame %dx%d(+%d) are not congruent", dz->h, dz->w, dz->pad, x->h, x->w, x->pad);
+    DBX_REQUIRE(x->h + 2 * cpad - kh + 1 == dz->h && x->w + 2 * cpad - kw + 1 == dz->w, "wgrad: dz is not the conv output shape");
+    DBX_REQUIRE(co <= dz->c && ci <= x->c, "wgrad: real channel counts exceed the views");
+    DBX_REQUIRE(((size_t)dz->ptr % 16) == 0 && ((size_t)x->ptr % 16) == 0 && (dz->ld * ES) % 16 == 0 && (x->ld * ES) % 16 == 0 &&
+                    (dz->c_off * ES) % 16 == 0 && (x->c_off * ES) % 16 == 0 && (dz->c * ES) % 16 == 0 && (x->c * ES) % 16 == 0,
+                "wgrad: 16-byte alignment");
+    const WgradPlan p = wgrad_plan(dz, x, kh, kw);
+    WgradArgs a;
+    a.dz = (const char*)dz->ptr + (size_t)dz->c_off * ES;
+    a.x = (const char*)x->ptr + (size_t)x->c_off * ES;
+    a.partial = (float*)scratch;
+    a.bpartial = db ? (float*)scratch + (size_t)p.splits * p.co_pad * p.taps * p.ci_pad : nullptr;
+    a.Q = p.Q; a.dz_ld = dz->ld; a.x_ld = x->ld; a.dz_c = dz->c; a.x_c = x->c;
+    a.co_pad = p.co_pad; a.ci_pad = p.ci_pad; a.taps = p.taps; a.kw = kw; a.wp = x->w + 2 * x->pad;
+    a.shift0 = x->pad - dz->pad - cpad;
+    a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci; a.rows_per_split = p.rows_per_split;
+    const dim3 grid(p.tiles_co * p.tiles_ci * p.taps, p.splits);
+    if (p.bmc == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, dim3(256), 0, s, a);
+    DBX_LAUNCH_CHECK();
+    const long long total = (long long)co * p.taps * ci + co;
+    int blocks = (int)((total + 255) / 256); blocks = blocks > 4096 ? 4096 : blocks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, co, ci, p.taps, p.co_pad,
+                       p.ci_pad, dw, db, accumulate);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+extern "C" int dbx_conv_wgrad(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, int32_t cpad,
+                              int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch, int32_t accumulate, void* stream) {
+    if (!dz || !x || !dw_oihw || !scratch) { dbx_set_error("wgrad: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(dtype, wgrad_t, dz, x, kh, kw, cpad, co, ci, dw_oihw, db, scratch, accumulate, (hipStream_t)stream);
+}

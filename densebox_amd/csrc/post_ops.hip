@@ -1,0 +1,193 @@
+// SGD(momentum, weight decay) multi-tensor update and the inference tail: top-K decode + greedy NMS.
+// Index bookkeeping must be bit-exact against NumPy/torch-CPU, so floating-point contraction is OFF in this
+// file: `areas[i] + areas[j] - w*h` must round the product before the subtraction like NumPy does.
+#pragma clang fp contract(off)
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------------------- SGD (DenseBox.py:2001-2004)
+// torch.optim.SGD, dampening 0, no Nesterov: g = grad + wd*p; buf = g (first step) | mu*buf + g; p -= lr*buf
+__global__ void sgd_kernel(float* const* __restrict__ ptrs, const long long* __restrict__ sizes, float lr, float mu, float wd,
+                           int first) {
+    const int t = blockIdx.y;
+    float* p = ptrs[3 * t];
+    const float* g = ptrs[3 * t + 1];
+    float* b = ptrs[3 * t + 2];
+    const long long n = sizes[t];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float pv = p[i];
+        const float gv = g[i] + wd * pv;
+        const float bv = first ? gv : mu * b[i] + gv;
+        b[i] = bv;
+        p[i] = pv - lr * bv;
+    }
+}
+extern "C" int dbx_sgd_step(float* const* ptrs, const int64_t* sizes, int32_t count, int64_t max_size, float lr, float momentum,
+                            float weight_decay, int32_t first_step, void* stream) {
+    DBX_REQUIRE(ptrs && sizes && count > 0, "sgd: empty parameter list");
+    int bx = (int)((max_size + 255) / 256);
+    bx = bx < 1 ? 1 : (bx > 512 ? 512 : bx);
+    hipLaunchKernelGGL(sgd_kernel, dim3(bx, count), dim3(256), 0, (hipStream_t)stream, ptrs, (const long long*)sizes, lr, momentum,
+                       weight_decay, first_step);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- top-K + decode
+#define DET_THREADS 1024
+
+__device__ __forceinline__ void block_argmax_g(const float* vals, int n, float* red_v, int* red_i, float& ov, int& oi) {
+    const int tid = threadIdx.x;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int i = tid; i < n; i += DET_THREADS) {
+        const float v = vals[i];
+        if (v > bv || bi == 0x7fffffff) { bv = v; bi = i; }        // lower index wins ties; first element seeds
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float v2 = __shfl_down(bv, off); const int i2 = __shfl_down(bi, off);
+        if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; }
+    }
+    if ((tid & 63) == 0) { red_v[tid >> 6] = bv; red_i[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < DET_THREADS / 64; ++w) {
+            const float v2 = red_v[w]; const int i2 = red_i[w];
+            if (i2 != 0x7fffffff && (bi == 0x7fffffff || v2 > bv || (v2 == bv && i2 < bi))) { bv = v2; bi = i2; }
+        }
+        red_v[0] = bv; red_i[0] = bi;
+    }
+    __syncthreads();
+    ov = red_v[0]; oi = red_i[0];
+    __syncthreads();
+}
+
+// greedy NMS over dets[n][dc] (float64): keep list in `keep` (keep[0] = count).  order = score descending, ties by
+// higher row index first (= numpy argsort(stable)[::-1]; DenseBox.py:3415).
+__device__ void nms_block(const double* dets, int n, int dc, double thresh, int* keep, int* order, unsigned char* supp) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < n; i += nt) {
+        const double si = dets[(size_t)i * dc + 4];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const double sj = dets[(size_t)j * dc + 4];
+            rank += (sj > si) || (sj == si && j > i);
+        }
+        order[rank] = i;
+        supp[i] = 0;
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int pos = 0; pos < n; ++pos) {
+        const int i = order[pos];
+        if (supp[i]) continue;                                  // uniform: supp[] only changes between barriers
+        if (tid == 0) keep[1 + cnt] = i;
+        ++cnt;
+        const double x1 = dets[(size_t)i * dc], y1 = dets[(size_t)i * dc + 1], x2 = dets[(size_t)i * dc + 2], y2 = dets[(size_t)i * dc + 3];
+        const double ai = (x2 - x1 + 1) * (y2 - y1 + 1);
+        for (int q = pos + 1 + tid; q < n; q += nt) {
+            const int j = order[q];
+            if (supp[j]) continue;
+            const double u1 = dets[(size_t)j * dc], v1 = dets[(size_t)j * dc + 1], u2 = dets[(size_t)j * dc + 2], v2 = dets[(size_t)j * dc + 3];
+            const double aj = (u2 - u1 + 1) * (v2 - v1 + 1);
+            const double xx1 = fmax(x1, u1), yy1 = fmax(y1, v1), xx2 = fmin(x2, u2), yy2 = fmin(y2, v2);
+            const double w = fmax(0.0, xx2 - xx1 + 1), h = fmax(0.0, yy2 - yy1 + 1);
+            const double inter = w * h;
+            const double ovr = inter / (ai + aj - inter);
+            if (!(ovr <= thresh)) supp[j] = 1;                   // NaN is dropped, like np.where(ovr <= t)
+        }
+        __syncthreads();
+    }
+    if (tid == 0) keep[0] = cnt;
+}
+
+struct DetArgs {
+    const float* score; const float* loc; const float* lm_heat; const float* lm_loc;
+    int rows, cols, K, dc; double thresh;
+    double* dets; long long* topk; int* keep; float* work; int* order; unsigned char* supp;
+};
+
+__global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
+    __shared__ float red_v[DET_THREADS / 64];
+    __shared__ int red_i[DET_THREADS / 64];
+    __shared__ int lm_arg[4];
+    const int tid = threadIdx.x, n = a.rows * a.cols;
+    for (int i = tid; i < n; i += DET_THREADS) a.work[i] = a.score[i];
+    __syncthreads();
+    // landmark arg-max per heat-map channel (parse_DetLM, DenseBox.py:3284-3292): identical for every detection
+    if (a.lm_heat && !a.lm_loc) {
+        for (int j = 0; j < 4; ++j) {
+            float v; int idx;
+            block_argmax_g(a.lm_heat + (size_t)j * n, n, red_v, red_i, v, idx);
+            if (tid == 0) lm_arg[j] = idx;
+        }
+        __syncthreads();
+    }
+    for (int k = 0; k < a.K; ++k) {
+        float v; int idx;
+        block_argmax_g(a.work, n, red_v, red_i, v, idx);
+        if (tid == 0) {
+            a.work[idx] = -INFINITY;
+            a.topk[k] = idx;
+            const float xi = (float)(idx % a.cols), yi = (float)(idx / a.cols);
+            double* d = a.dets + (size_t)k * a.dc;
+            // fp32 subtraction (python int - fp32 tensor), then float()*4.0 in double (DenseBox.py:3334-3343)
+            d[0] = (double)(xi - a.loc[idx]) * 4.0;
+            d[1] = (double)(yi - a.loc[(size_t)n + idx]) * 4.0;
+            d[2] = (double)(xi - a.loc[(size_t)2 * n + idx]) * 4.0;
+            d[3] = (double)(yi - a.loc[(size_t)3 * n + idx]) * 4.0;
+            d[4] = (double)a.score[idx];
+            if (a.dc == 13) {
+                if (a.lm_loc) {
+                    for (int c = 0; c < 8; ++c)
+                        d[5 + c] = (double)(((c & 1) ? yi : xi) - a.lm_loc[(size_t)c * n + idx]) * 4.0;   // :3183-3196
+                } else {
+                    for (int j = 0; j < 4; ++j) {
+                        d[5 + 2 * j] = (double)(float)(lm_arg[j] % a.cols) * 4.0;
+                        d[6 + 2 * j] = (double)(float)(lm_arg[j] / a.cols) * 4.0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    nms_block(a.dets, a.K, a.dc, a.thresh, a.keep, a.order, a.supp);
+}
+
+extern "C" int64_t dbx_detect_scratch_bytes(int32_t rows, int32_t cols, int32_t K) {
+    return (int64_t)rows * cols * 4 + (int64_t)K * 4 + (int64_t)K + 256;
+}
+
+extern "C" int dbx_detect(const float* score, const float* loc, const float* lm_heat, const float* lm_loc, int32_t rows,
+                          int32_t cols, int32_t K, double nms_thresh, double* dets, int32_t det_cols, int64_t* topk_idx,
+                          int32_t* keep, void* scratch, void* stream) {
+    DBX_REQUIRE(score && loc && dets && topk_idx && keep && scratch, "detect: null argument");
+    DBX_REQUIRE(K > 0 && K <= rows * cols, "detect: K=%d out of range", K);
+    DBX_REQUIRE(det_cols == 5 || (det_cols == 13 && (lm_heat || lm_loc)), "detect: det_cols must be 5, or 13 with landmark maps");
+    DetArgs a;
+    a.score = score; a.loc = loc; a.lm_heat = lm_heat; a.lm_loc = lm_loc;
+    a.rows = rows; a.cols = cols; a.K = K; a.dc = det_cols; a.thresh = nms_thresh;
+    a.dets = dets; a.topk = (long long*)topk_idx; a.keep = keep;
+    char* s = (char*)scratch;
+    a.work = (float*)s; s += (size_t)rows * cols * 4;
+    a.order = (int*)s; s += (size_t)K * 4;
+    a.supp = (unsigned char*)s;
+    hipLaunchKernelGGL(detect_kernel, dim3(1), dim3(DET_THREADS), 0, (hipStream_t)stream, a);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+__global__ __launch_bounds__(DET_THREADS) void nms_kernel(const double* dets, int n, int dc, double thresh, int* keep, int* order,
+                                                          unsigned char* supp) {
+    nms_block(dets, n, dc, thresh, keep, order, supp);
+}
+extern "C" int dbx_nms(const double* dets, int32_t n, int32_t det_cols, double nms_thresh, int32_t* keep, void* scratch,
+                       void* stream) {
+    DBX_REQUIRE(dets && keep && scratch && n > 0 && det_cols >= 5, "nms: bad arguments");
+    int* order = (int*)scratch;
+    unsigned char* supp = (unsigned char*)scratch + (size_t)n * 4;
+    hipLaunchKernelGGL(nms_kernel, dim3(1), dim3(DET_THREADS), 0, (hipStream_t)stream, dets, n, det_cols, nms_thresh, keep, order, supp);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}

@@ -1,0 +1,80 @@
+"""Inference tail on the GPU: top-K decode (parse_output / parse_out_MN / parse_DetLM / parse_DetLMLOC,
+DenseBox.py:3114-3395) and greedy NMS (DenseBox.py:3398-3443), same names, arguments and results
+(float64 ``np.ndarray`` rows in descending-score order, python list of kept row indices)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+def _run(score_map, loc_map, M, N, K, lm_heat=None, lm_loc=None, nms_thresh=0.4):
+    rows, cols = M // 4, N // 4
+    assert score_map.size() == torch.Size([1, 1, rows, cols])
+    assert loc_map.size() == torch.Size([1, 4, rows, cols])
+    if lm_heat is not None:
+        assert lm_heat.size() == torch.Size([1, 4, rows, cols])
+    if lm_loc is not None:
+        assert lm_loc.size() == torch.Size([1, 8, rows, cols])
+    dev = score_map.device if score_map.is_cuda else torch.device('cuda')
+
+    def f(t):
+        return None if t is None else t.detach().to(dev, torch.float32).contiguous()
+    s, l, hm, ll = f(score_map), f(loc_map), f(lm_heat), f(lm_loc)
+    dc = 5 if (hm is None and ll is None) else 13
+    dets = torch.empty((K, dc), dtype=torch.float64, device=dev)
+    topk = torch.empty(K, dtype=torch.int64, device=dev)
+    keep = torch.empty(K + 1, dtype=torch.int32, device=dev)
+    L = _lib.lib()
+    scratch = torch.empty(L.dbx_detect_scratch_bytes(rows, cols, K), dtype=torch.uint8, device=dev)
+    check(L.dbx_detect(ptr(s), ptr(l), ptr(hm), ptr(ll), rows, cols, K, float(nms_thresh), ptr(dets), dc, ptr(topk),
+                       ptr(keep), ptr(scratch), stream_ptr()))
+    return dets, topk, keep
+
+
+def parse_out_MN(score_map, loc_map, M, N, K=10):
+    return _run(score_map, loc_map, M, N, K)[0].cpu().numpy()
+
+
+def parse_output(score_map, loc_map, K=10):
+    assert score_map.size() == torch.Size([1, 1, 60, 60])
+    return parse_out_MN(score_map, loc_map, 240, 240, K)
+
+
+def parse_DetLM(score_map, loc_map, lm_map, M, N, K=10):
+    return _run(score_map, loc_map, M, N, K, lm_heat=lm_map)[0].cpu().numpy()
+
+
+def parse_DetLMLOC(score_map, bbox_loc_map, lm_heat_map, lm_loc_map, M, N, K=10):
+    return _run(score_map, bbox_loc_map, M, N, K, lm_heat=lm_heat_map, lm_loc=lm_loc_map)[0].cpu().numpy()
+
+
+def NMS(dets, nms_thresh=0.4):
+    d = torch.as_tensor(np.ascontiguousarray(dets, dtype=np.float64)).cuda()
+    n, dc = d.shape
+    keep = torch.empty(n + 1, dtype=torch.int32, device=d.device)
+    scratch = torch.empty(5 * n + 16, dtype=torch.uint8, device=d.device)
+    check(_lib.lib().dbx_nms(ptr(d), n, dc, float(nms_thresh), ptr(keep), ptr(scratch), stream_ptr()))
+    k = keep.cpu().numpy()
+    return [int(v) for v in k[1:1 + int(k[0])]]
+
+
+def detect(net, image, K=10, nms_thresh=0.4):
+    """Whole-image forward -> top-K -> decode -> NMS in one go (test / test_lm / test_lmloc drivers,
+    DenseBox.py:3788-3799, :3626-3643, :3709-3726): ranks by the refined score for the landmark nets.
+    Returns (dets[K, 5|13] float64 ndarray, keep list)."""
+    assert image.dim() == 4 and image.size(0) == 1
+    M, N = image.size(2), image.size(3)
+    with torch.no_grad():
+        outs = net(image)
+    kind = net.KIND
+    if kind == 'DenseBox':
+        dets, _, keep = _run(outs[0], outs[1], M, N, K, nms_thresh=nms_thresh)
+    elif kind == 'DenseBoxLM':
+        dets, _, keep = _run(outs[3], outs[1], M, N, K, lm_heat=outs[2], nms_thresh=nms_thresh)
+    else:
+        dets, _, keep = _run(outs[1], outs[2], M, N, K, lm_heat=outs[3], lm_loc=outs[4], nms_thresh=nms_thresh)
+    k = keep.cpu().numpy()
+    return dets.cpu().numpy(), [int(v) for v in k[1:1 + int(k[0])]]

@@ -71,9 +71,11 @@ class Plan:
         add('a41', h8, w8, 512); add('a42', h8, w8, 512); add('a43', h8, w8, 512); add('a44', h8, w8, 512)
         add('hid', h4, w4, 512 * nh, pad=0)
         if kind != 'DenseBox':
+            # frames chosen so that each conv's (dz, x) pair is congruent for the weight gradient AND dz has the
+            # k-1 pixel frame its data gradient needs: rf_p(+1) ~ d_rf_1(+2), rf_1(+2) ~ d_rf_2(+4)
             add('rf_in', h4, w4, self.crf, pad=0)
-            add('rf_p', h8, w8, self.crf, pad=0)
-            add('rf_1', h8 - 2, w8 - 2, 64, pad=0)
+            add('rf_p', h8, w8, self.crf, pad=1)
+            add('rf_1', h8 - 2, w8 - 2, 64, pad=2)
             add('rf_2', h8 - 6, w8 - 6, 64, pad=0)
             add('rf_u', h4, w4, 64, pad=0)
         if train:
@@ -83,12 +85,13 @@ class Plan:
             add('d_c34', h4, w4, 256)
             add('d_ups', h4, w4, 512, pad=0)
             add('d_p1', h2, w2, 64, pad=0); add('d_p2', h4, w4, 128, pad=0); add('d_p3', h8, w8, 256, pad=0)
-            add('d_hid', h4, w4, 512 * nh, pad=0)
+            add('d_hid', h4, w4, 512 * nh, pad=1)         # congruent with 'fusion'
             add('d_out', h4, w4, self.crf * nh, pad=0)    # dL/d(head outputs), one crf-channel slot per head
             if kind != 'DenseBox':
+                add('d_rfo', h4, w4, self.crf, pad=0)
                 add('d_rf_u', h4, w4, 64, pad=0)
-                add('d_rf_2', h8 - 2, w8 - 2, 64, pad=4)     # framed like rf_1 (5x5 dgrad needs a 4-px frame)
-                add('d_rf_1', h8, w8, 64, pad=2)             # framed like rf_p (3x3 dgrad needs a 2-px frame)
+                add('d_rf_2', h8 - 6, w8 - 6, 64, pad=4)
+                add('d_rf_1', h8 - 2, w8 - 2, 64, pad=2)
                 add('d_rf_p', h8, w8, self.crf, pad=0)
                 add('d_rf_in', h4, w4, self.crf, pad=0)
         off = 0
@@ -250,7 +253,8 @@ class Engine:
         nh = len(heads)
         epi = _lib.EPI_BIAS
         dm = None
-        if train:
+        P.drop_active = bool(train and self._dropout_p() > 0.0)
+        if P.drop_active:
             dm = P.mask_ptr
             self._fill_dropout(P, heads)
             epi |= _lib.EPI_DROPMASK
@@ -283,6 +287,14 @@ class Engine:
             outs['refine'] = o
         return outs
 
+    def _dropout_p(self):
+        """nn.Dropout() of the heads (DenseBox.py:160): the reference default p=0.5 or 0 (disabled)."""
+        drops = [m for m in self.net.modules() if isinstance(m, torch.nn.Dropout)]
+        p = drops[0].p if drops else 0.0
+        if p not in (0.0, 0.5):
+            raise RuntimeError('densebox_amd: the head Dropout supports p=0.5 (reference) or p=0, got %r' % p)
+        return p
+
     def _fill_dropout(self, P, heads):
         """Training-mode keep-masks: injected (parity) or drawn by the device RNG."""
         nh = len(heads)
@@ -306,3 +318,138 @@ class Engine:
         out = torch.empty((b.n, v.c, b.h, b.w), dtype=torch.float32, device=P.ws.device)
         check(self.L.dbx_framed_to_nchw_f32(P.dtype_id, C.byref(v), ptr(out), stream_ptr()))
         return out
+
+    # ------------------------------------------------------------------ backward
+    def _w_bwd(self, dt, stem, rows_pad, cin_pad):
+        """dgrad weights: rows = input channels, K = [flipped tap][output channel]."""
+        w = self._param(stem + '.weight')
+        return self._packed((stem, 1, dt), lambda: self._pack(dt, 1, w, rows_pad, cin_pad, w.shape[2], w.shape[3]),
+                            (w._version, w.data_ptr()))
+
+    def _w_heads1_bwd(self, dt):
+        heads = _HEADS[self.kind]
+        ws = [self._param('conv5_1_%s.weight' % s) for s, _ in heads]
+
+        def build():
+            out = None
+            for i, w in enumerate(ws):
+                out = self._pack(dt, 1, w, 768, 512 * len(ws), 1, 1, out=out, k_off=512 * i)
+            return out
+        return self._packed(('heads1', 1, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+
+    def _wgrad(self, dt, dz, x, kh, kw, cpad, co, ci, dw, db, accumulate=0):
+        need = self.L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dz), C.byref(x), kh, kw)
+        if getattr(self, '_wg_scratch', None) is None or self._wg_scratch.numel() < need:
+            self._wg_scratch = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=dw.device)
+        check(self.L.dbx_conv_wgrad(dt, C.byref(dz), C.byref(x), kh, kw, cpad, co, ci, ptr(dw), ptr(db),
+                                    ptr(self._wg_scratch), accumulate, stream_ptr()))
+
+    def backward_raw(self, grad_outs):
+        """grad_outs: dict output-name -> fp32 NCHW tensor (or None).  Returns dict param-name -> fp32 gradient.
+        Must follow a forward_raw(train=True) on the same plan (activations are read from the workspace)."""
+        L, kind = self.L, self.kind
+        P = self.last_plan
+        assert P is not None and P.train, 'backward needs a preceding training-mode forward'
+        B, dt, n = P.B, P.dtype_id, P.n
+        s = stream_ptr()
+        dev = P.ws.device
+        heads = _HEADS[kind]
+        nh = len(heads)
+        h4, w4 = P.h4, P.w4
+        G = {}
+
+        def new_grad(name):
+            p = self._param(name)
+            g = torch.empty_like(p, dtype=torch.float32)
+            G[name] = g
+            return g
+
+        def gout(name, k):
+            g = grad_outs.get(name)
+            if g is None:
+                return torch.zeros((n, k, h4, w4), dtype=torch.float32, device=dev)
+            return g.to(torch.float32).contiguous()
+
+        def conv_bwd(stem, dz, x, kh, kw, cpad, co, ci):
+            self._wgrad(dt, dz, x, kh, kw, cpad, co, ci, new_grad(stem + '.weight'), new_grad(stem + '.bias'))
+
+        def dgrad(stem, src, dst, kh, kw, cpad, rows_pad, cin_pad, gate=None, epi=0, dropmask=None):
+            wp = self._w_bwd(dt, stem, rows_pad, cin_pad)
+            e = epi | (_lib.EPI_GATE if gate is not None else 0)
+            self._conv(dt, src, dst, wp, None, kh, kw, cpad, cin_pad, rows_pad, e, gate=gate, dropmask=dropmask,
+                       dm_ld=512 * nh)
+
+        # ---- refine branch (DenseBox.py:464-471) backwards
+        if kind != 'DenseBox':
+            d_rfo = B['d_rfo'].view()
+            check(L.dbx_nchw_to_framed(dt, ptr(gout('refine', 1)), 1, C.byref(d_rfo), s))
+            conv_bwd('conv6_3_det', d_rfo, B['rf_u'].view(), 1, 1, 0, 1, 64)
+            dgrad('conv6_3_det', d_rfo, B['d_rf_u'].view(), 1, 1, 0, 64, P.crf)
+            check(L.dbx_upsample_bilinear_bwd(dt, C.byref(B['d_rf_u'].view()), C.byref(B['d_rf_2'].view()), None, s))
+            conv_bwd('conv6_2_det', B['d_rf_2'].view(), B['rf_1'].view(), 5, 5, 0, 64, 64)
+            dgrad('conv6_2_det', B['d_rf_2'].view(), B['d_rf_1'].view(), 5, 5, 4, 64, 64)
+            conv_bwd('conv6_1_det', B['d_rf_1'].view(), B['rf_p'].view(), 3, 3, 0, 64, 5)
+            dgrad('conv6_1_det', B['d_rf_1'].view(), B['d_rf_p'].view(), 3, 3, 2, 64, 64)
+            check(L.dbx_maxpool2x2_bwd(dt, C.byref(B['rf_in'].view()), C.byref(B['d_rf_p'].view()),
+                                       C.byref(B['d_rf_in'].view()), 0, 0, s))
+
+        # ---- head outputs: dL/dout into the per-head slots (+ the refine input gradient)
+        slot = {}
+        for i, (stem, k) in enumerate(heads):
+            slot[stem] = B['d_out'].view(P.crf * i, P.crf)
+            check(L.dbx_nchw_to_framed(dt, ptr(gout(stem, k)), k, C.byref(slot[stem]), s))
+        if kind != 'DenseBox':
+            check(L.dbx_framed_add_ch(dt, C.byref(B['d_rf_in'].view()), 0, 4, C.byref(slot['landmark']), 0, s))
+            check(L.dbx_framed_add_ch(dt, C.byref(B['d_rf_in'].view()), 4, 1, C.byref(slot['det']), 0, s))
+
+        # ---- heads: 512 -> k (per head), dropout, then the shared 768 -> 512*nh GEMM
+        for i, (stem, k) in enumerate(heads):
+            conv_bwd('conv5_2_' + stem, slot[stem], B['hid'].view(512 * i, 512), 1, 1, 0, k, 512)
+            dgrad('conv5_2_' + stem, slot[stem], B['d_hid'].view(512 * i, 512), 1, 1, 0, 512, P.crf,
+                  epi=_lib.EPI_DROPMASK if P.drop_active else 0,
+                  dropmask=(P.mask_ptr + 512 * i) if P.drop_active else None)
+        dw1 = torch.empty((512 * nh, 768, 1, 1), dtype=torch.float32, device=dev)
+        db1 = torch.empty((512 * nh,), dtype=torch.float32, device=dev)
+        self._wgrad(dt, B['d_hid'].view(), B['fusion'].view(), 1, 1, 0, 512 * nh, 768, dw1, db1)
+        for i, (stem, _) in enumerate(heads):
+            G['conv5_1_%s.weight' % stem] = dw1[512 * i:512 * (i + 1)]
+            G['conv5_1_%s.bias' % stem] = db1[512 * i:512 * (i + 1)]
+        w1t = self._w_heads1_bwd(dt)                          # [768 rows][512*nh]
+        row_bytes = 512 * nh * _lib.ESIZE[dt]
+        c34 = B['fusion'].view(512, 256)
+        self._conv(dt, B['d_hid'].view(), B['d_ups'].view(), w1t, None, 1, 1, 0, 512 * nh, 512, 0)
+        self._conv(dt, B['d_hid'].view(), B['d_c34'].view(), w1t[512 * row_bytes:], None, 1, 1, 0, 512 * nh, 256,
+                   _lib.EPI_GATE, gate=c34)
+        check(L.dbx_upsample_bilinear_bwd(dt, C.byref(B['d_ups'].view()), C.byref(B['d_a44'].view()),
+                                          C.byref(B['a44'].view()), s))
+
+        # ---- backbone, deepest first.  (stem, dz, x, cin, cout, where the data gradient goes, its ReLU gate)
+        chain = [
+            ('conv4_4_1', 'd_a44', 'a43', 512, 512, 'd_a43', 'a43'),
+            ('conv4_3_1', 'd_a43', 'a42', 512, 512, 'd_a42', 'a42'),
+            ('conv4_2_1', 'd_a42', 'a41', 512, 512, 'd_a41', 'a41'),
+            ('conv4_1_1', 'd_a41', 'p3', 256, 512, 'd_p3', None),
+            ('pool', 'fusion', 'd_p3', 'd_c34', 1),
+            ('conv3_4_1', 'd_c34', 'a32', 256, 256, 'd_a32', 'a32'),
+            ('conv3_2_1', 'd_a32', 'a31', 256, 256, 'd_a31', 'a31'),
+            ('conv3_1_1', 'd_a31', 'p2', 128, 256, 'd_p2', None),
+            ('pool', 'a22', 'd_p2', 'd_a22', 0),
+            ('conv2_2_1', 'd_a22', 'a21', 128, 128, 'd_a21', 'a21'),
+            ('conv2_1_1', 'd_a21', 'p1', 64, 128, 'd_p1', None),
+            ('pool', 'a12', 'd_p1', 'd_a12', 0),
+            ('conv1_2_1', 'd_a12', 'a11', 64, 64, 'd_a11', 'a11'),
+            ('conv1_1_1', 'd_a11', 'x0', 3, 64, None, None),
+        ]
+        for item in chain:
+            if item[0] == 'pool':
+                _, xname, dyname, dxname, acc = item
+                xv = c34 if xname == 'fusion' else B[xname].view()
+                check(L.dbx_maxpool2x2_bwd(dt, C.byref(xv), C.byref(B[dyname].view()), C.byref(B[dxname].view()),
+                                           acc, 1, s))
+                continue
+            stem, dzn, xn, cin, cout, dxn, gaten = item
+            conv_bwd(stem, B[dzn].view(), B[xn].view(), 3, 3, 1, cout, cin)
+            if dxn is not None:
+                dgrad(stem, B[dzn].view(), B[dxn].view(), 3, 3, 1, max(64, cin), cout,
+                      gate=B[gaten].view() if gaten else None)
+        return G

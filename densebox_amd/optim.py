@@ -1,0 +1,70 @@
+"""Fused multi-tensor SGD with the semantics of the reference's optimizer
+(``torch.optim.SGD(net.parameters(), lr, momentum=0.9, weight_decay=5e-8)``, DenseBox.py:2001-2004)
+and its epoch schedule ``adjust_LR`` (DenseBox.py:1345-1365).  One HIP launch updates every tensor."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+
+class SGD:
+    def __init__(self, params, lr, momentum=0.9, weight_decay=5e-8):
+        self.params = [p for p in params]
+        self.param_groups = [{'lr': lr, 'momentum': momentum, 'weight_decay': weight_decay, 'params': self.params}]
+        self.bufs = {}
+        self._table = None
+        self._key = None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None if set_to_none else (p.grad.zero_() if p.grad is not None else None)
+
+    def step(self):
+        g = self.param_groups[0]
+        live = [p for p in self.params if p.grad is not None]          # conv3_3 never gets one (DenseBox.py:193-195)
+        if not live:
+            return
+        first = [p for p in live if id(p) not in self.bufs]
+        if first and len(first) != len(live):
+            # mixed first/subsequent steps: give the newcomers a zero buffer (mu*0 + g == g)
+            for p in first:
+                self.bufs[id(p)] = torch.zeros_like(p, dtype=torch.float32)
+            first = []
+        for p in first:
+            self.bufs[id(p)] = torch.empty_like(p, dtype=torch.float32)
+        grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in live]
+        key = tuple((p.data_ptr(), gr.data_ptr()) for p, gr in zip(live, grads))
+        dev = live[0].device
+        if key != self._key:
+            tab = []
+            for p, gr in zip(live, grads):
+                assert p.dtype == torch.float32 and p.is_contiguous() and gr.dtype == torch.float32
+                tab += [p.data_ptr(), gr.data_ptr(), self.bufs[id(p)].data_ptr()]
+            self._table = (torch.tensor(tab, dtype=torch.int64, device=dev),
+                           torch.tensor([p.numel() for p in live], dtype=torch.int64, device=dev),
+                           max(p.numel() for p in live))
+            self._key = key
+        ptrs, sizes, mx = self._table
+        with torch.no_grad():
+            check(_lib.lib().dbx_sgd_step(ptr(ptrs), ptr(sizes), len(live), mx, g['lr'], g['momentum'],
+                                          g['weight_decay'], 1 if first else 0, stream_ptr()))
+            # the kernel wrote the parameters behind autograd's back: bump their version counters so that
+            # autograd and the engine's packed-weight cache see the update
+            torch.autograd.graph.increment_version(live)
+
+
+def adjust_LR(optimizer, epoch):
+    """DenseBox.py:1345-1365: absolute LR per epoch (ignores base_lr)."""
+    if epoch < 5:
+        lr = 1e-9
+    elif epoch < 10:
+        lr = 2e-9
+    elif epoch < 15:
+        lr = 4e-9
+    else:
+        lr = 1e-9
+    for grp in optimizer.param_groups:
+        grp['lr'] = lr
+    return lr

@@ -93,8 +93,10 @@ int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw, int32_t co
  * `partial` is a scratch buffer of dbx_conv_wgrad_scratch_bytes(); the reduction over it is deterministic.
  */
 int64_t dbx_conv_wgrad_scratch_bytes(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw);
+/* co/ci: real channel counts of dw_oihw [co][ci][kh][kw] (the views may be wider: padded channels are dropped).
+ * db may be NULL.  accumulate != 0 adds into dw/db instead of overwriting. */
 int dbx_conv_wgrad(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, int32_t cpad,
-                   float* dw_oihw, float* db, void* partial, void* stream);
+                   int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------ layout / pooling / resampling
  * nchw_to_framed: network input X (DenseBox.py:185) fp32 NCHW -> framed NHWC compute dtype (channels padded with 0).
@@ -109,6 +111,9 @@ int dbx_nchw_to_framed(int32_t dtype, const float* x_nchw, int32_t c_src, const 
 int dbx_nchw_to_framed_ch(int32_t dtype, const float* x_nchw, int32_t c_src, const dbx_view* y, int32_t c_dst_off,
                           void* stream);
 int dbx_framed_to_nchw_f32(int32_t dtype, const dbx_view* x, float* y_nchw, void* stream);
+/* dst[..., c_dst_off+j] += src[..., c_src_off+j], j < n_ch (gradient of the channel concat at DenseBox.py:464) */
+int dbx_framed_add_ch(int32_t dtype, const dbx_view* src, int32_t c_src_off, int32_t n_ch, const dbx_view* dst,
+                      int32_t c_dst_off, void* stream);
 /* nn.Dropout(p=0.5) keep-mask bytes {0,1} from a counter-based device RNG (DenseBox.py:160); nbytes % 16 == 0 */
 int dbx_dropout_mask(uint8_t* mask, int64_t nbytes, uint64_t seed, void* stream);
 int dbx_maxpool2x2(int32_t dtype, const dbx_view* x, const dbx_view* y, void* stream);
@@ -147,7 +152,8 @@ typedef struct dbx_loss_io {
     int32_t* pos_count;      /* [n] positives per sample out or NULL */
 } dbx_loss_io;
 
-int dbx_loss_forward_backward(const dbx_loss_desc* d, const dbx_loss_io* io, void* stream);
+/* scratch: d->n doubles (per-patch partial sums, reduced in fixed order) */
+int dbx_loss_forward_backward(const dbx_loss_desc* d, const dbx_loss_io* io, void* scratch, void* stream);
 /* positives per sample from the boxes alone (a5) -- lets the host derive half_neg without reading maps back */
 int dbx_count_positives(const float* bbox, const float* labels, int32_t n, int32_t* count_per_sample, void* stream);
 
@@ -174,7 +180,8 @@ int dbx_detect(const float* score, const float* loc, const float* lm_heat, const
                int32_t rows, int32_t cols, int32_t K, double nms_thresh,
                double* dets, int32_t det_cols, int64_t* topk_idx, int32_t* keep, void* scratch, void* stream);
 int64_t dbx_detect_scratch_bytes(int32_t rows, int32_t cols, int32_t K);
-int dbx_nms(const double* dets, int32_t n, int32_t det_cols, double nms_thresh, int32_t* keep, void* stream);
+/* scratch: 5*n bytes */
+int dbx_nms(const double* dets, int32_t n, int32_t det_cols, double nms_thresh, int32_t* keep, void* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,145 @@
+"""GPU parity of the full training step (forward -> fused loss -> HIP backward -> fused SGD) against the
+gradients / parameter updates captured from the reference's own training loops."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import unpack
+from densebox_amd import synth
+from densebox_amd.optim import SGD, adjust_LR
+import densebox_amd as D
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def _setup(golden, name, dtype):
+    g = golden(name)
+    kind = str(g['kind'])
+    net = getattr(D, kind)(synth.vgg19_standin(seed=0))
+    synth.fill_params_(net, int(g['param_seed']))
+    net = net.cuda().train()
+    net.compute_dtype = dtype
+    n = int(g['batch'])
+    if str(g['dropout']) == 'mask':
+        net.dropout_masks = {h: T(unpack(g['dropmask_%d' % i], (n, 512, 60, 60))) for i, h in enumerate(['det', 'loc'])}
+    else:
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+    x, _, _, _ = synth.synth_batch(int(g['n_patch']), seed=int(g['seed']))
+    return g, kind, net, n, x
+
+
+def _step(g, kind, net, n, x, step):
+    sl = slice(step * n, (step + 1) * n)
+    outs = net(x[sl].cuda())
+    p = 's%d_' % step
+    neg0 = g[p + 'neg_idx_0']
+    half = neg0.shape[1] // 2
+    lm_rand = None if kind == 'DenseBox' else np.stack([g[p + 'neg_idx_%d' % (1 + j)][:, 1:] for j in range(4)])
+    kw = {k[3:]: float(g[k]) for k in g.files if k.startswith('kw_')}
+    loss = net.loss(outs, g['bbox'][sl], g['vert'][sl], g['lab'][sl], rand_neg_indices=neg0[:, half:],
+                    lm_rand_neg_indices=lm_rand, **kw)
+    return outs, loss
+
+
+def _check_grads(g, net, step):
+    """Every layer above the last max-pool on its gradient path (conv4_*, heads, refine) must match element-wise
+    to fp32 round-off.  Below a pool the gradient is discontinuous in the activations: a 2x2 window whose two
+    largest values differ in the 7th digit can route its gradient to the other pixel on the GPU (observed: 2 of
+    460k windows), so there the check is the relative L2 error of the whole tensor."""
+    p = 's%d_' % step
+    for name, prm in net.named_parameters():
+        if p + 'gnone_' + name in g.files:
+            assert prm.grad is None, name          # conv3_3 is never executed (DenseBox.py:193-195)
+            continue
+        gr = prm.grad.detach().float().cpu().numpy()
+        stat = g[p + 'gstat_' + name]
+        l1 = np.abs(gr.reshape(-1).astype(np.float64)).sum()
+        assert np.isclose(l1, stat[1], rtol=2e-3), (name, l1, stat[1])
+        if p + 'g_' + name in g.files:
+            ref, got = g[p + 'g_' + name], gr
+        else:
+            ref, got = g[p + 'gsub_' + name], gr.reshape(-1)[::997]
+        ref64, got64 = ref.reshape(-1).astype(np.float64), got.reshape(-1).astype(np.float64)
+        rel_l2 = np.linalg.norm(got64 - ref64) / max(np.linalg.norm(ref64), 1e-300)
+        rel_max = np.abs(got64 - ref64).max() / max(np.abs(ref64).max(), 1e-300)
+        below_pool = name.startswith(('conv1_', 'conv2_', 'conv3_'))
+        if below_pool:
+            assert rel_l2 <= 5e-3 and rel_max <= 3e-2, (name, rel_l2, rel_max)
+        else:
+            assert rel_max <= 2e-4, (name, rel_max)
+
+
+@pytest.mark.parametrize('name', ['train_DenseBox', 'train_DenseBox_dropout', 'train_DenseBoxLM', 'train_DenseBoxLMLOC'])
+def test_training_step_f32_vs_reference(golden, name):
+    g, kind, net, n, x = _setup(golden, name, 'f32')
+    outs, loss = _step(g, kind, net, n, x, 0)
+    for i, o in enumerate(outs):
+        ref = g['s0_out_%d' % i]
+        assert np.allclose(o.detach().cpu().numpy(), ref, rtol=0, atol=1e-4 * max(1.0, np.abs(ref).max()))
+    assert np.isclose(float(loss.detach()), float(g['s0_loss']), rtol=1e-4)
+    loss.backward()
+    _check_grads(g, net, 0)
+
+
+def test_two_sgd_steps_f32_vs_reference(golden):
+    """forward/backward/step twice: momentum buffer, weight decay and the version-counter invalidation of the
+    packed-weight cache are all on the path (DenseBox.py:2001-2004, :2186-2187)."""
+    g, kind, net, n, x = _setup(golden, 'train_DenseBox', 'f32')
+    opt = SGD(net.parameters(), lr=float(g['lr']), momentum=0.9, weight_decay=5e-8)
+    for step in range(int(g['n_steps'])):
+        opt.zero_grad()
+        outs, loss = _step(g, kind, net, n, x, step)
+        assert np.isclose(float(loss.detach()), float(g['s%d_loss' % step]), rtol=2e-3), step
+        loss.backward()
+        opt.step()
+        for pname, prm in net.named_parameters():
+            key = 's%d_pa_%s' % (step, pname)
+            if key in g.files:
+                ref, before = g[key], g['s%d_pb_%s' % (step, pname)]
+                upd = np.abs(ref - before).max()
+                assert np.abs(prm.detach().cpu().numpy() - ref).max() <= 5e-3 * upd + 1e-9, (pname, step)
+    assert [adjust_LR(opt, e) for e in (0, 5, 10, 15)] == [1e-9, 2e-9, 4e-9, 1e-9]
+    assert opt.param_groups[0]['lr'] == 1e-9
+
+
+def test_sgd_kernel_exact_against_captured_grads(golden):
+    """The fused SGD kernel alone, fed the reference's captured gradients: parameters must match to 1 ulp-ish."""
+    g = golden('train_DenseBox')
+    names = ['conv1_1_1.weight', 'conv5_2_det.weight', 'conv5_2_loc.bias']
+    ps = [torch.nn.Parameter(T(g['s0_pb_' + n_]).cuda()) for n_ in names]
+    opt = SGD(ps, lr=float(g['lr']), momentum=0.9, weight_decay=5e-8)
+    for step in range(int(g['n_steps'])):
+        for p, n_ in zip(ps, names):
+            p.grad = T(g['s%d_g_%s' % (step, n_)]).cuda()
+        v0 = ps[0]._version
+        opt.step()
+        assert ps[0]._version > v0
+        for p, n_ in zip(ps, names):
+            ref = g['s%d_pa_%s' % (step, n_)]
+            assert np.allclose(p.detach().cpu().numpy(), ref, rtol=1e-6, atol=1e-9), (n_, step)
+
+
+@pytest.mark.parametrize('dtype,cos_min', [('bf16', 0.97), ('f16', 0.995)])
+def test_training_step_low_precision(golden, dtype, cos_min):
+    """bf16/f16 compute with fp32 accumulation: gradients stay aligned with the fp32 reference gradients."""
+    g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', dtype)
+    outs, loss = _step(g, kind, net, n, x, 0)
+    assert np.isclose(float(loss.detach()), float(g['s0_loss']), rtol=5e-2)
+    loss.backward()
+    worst = 1.0
+    for name, prm in net.named_parameters():
+        key = 's0_g_' + name
+        if key not in g.files:
+            continue
+        ref = g[key].reshape(-1).astype(np.float64)
+        got = prm.grad.detach().float().cpu().numpy().reshape(-1).astype(np.float64)
+        assert np.isfinite(got).all(), name
+        if np.abs(ref).max() == 0:
+            continue
+        cos = float(ref @ got / (np.linalg.norm(ref) * np.linalg.norm(got) + 1e-300))
+        worst = min(worst, cos)
+        assert cos >= cos_min, (name, cos)
+    print('worst cosine', dtype, worst)
