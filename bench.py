@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- DenseBox training throughput on MI355X (contract: one JSON line from rank 0).
+
+A "step" = one full training step of the reference loop body (DenseBox.py:2016-2187) on a batch of synthetic
+240x240 patches already resident in HBM: forward, fused dense loss with hard-negative mining, backward,
+gradient all-reduce over RCCL (N>1), fused SGD.  Workload = BASELINE.json configs[2]/[3]: DenseBoxLMLOC (the net
+the reference's __main__ trains: score + bbox + landmark heat-maps + landmark offsets + refine), batch 64 per GPU,
+bf16 compute / fp32 accumulate / fp32 master weights.  Weak scaling: per-GPU batch fixed.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import densebox_amd as D                      # noqa: E402
+from densebox_amd import synth, labels as LB  # noqa: E402
+from densebox_amd.dist import init_from_env, DataParallel  # noqa: E402
+from densebox_amd.optim import SGD            # noqa: E402
+
+# algorithmic FLOP per 240x240 patch (SURVEY.md 8d / BASELINE.md 2): forward, and forward+dgrad+wgrad
+FWD_GFLOP = {'DenseBox': 41.98, 'DenseBoxLM': 44.95, 'DenseBoxLMLOC': 47.81}
+STEP_GFLOP = {'DenseBox': 125.7, 'DenseBoxLM': 134.6, 'DenseBoxLMLOC': 143.2}
+MFMA_PEAK_TF = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}     # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops(eng_calls):
+    return sum(c['flops'] for c in eng_calls)
+
+
+def cpu_baseline(kind, seconds=20.0):
+    """Reference algorithm on the host cores: the CPU oracle (torch fp32 nn ops + numpy bookkeeping) running the same
+    training step on a bounded sample.  Reported baseline, not a target."""
+    from oracle import densebox_oracle as O
+    n = 4
+    net = getattr(D, kind)(synth.vgg19_standin(seed=0))
+    synth.fill_params_(net, 11)
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in net.named_parameters()}
+    x, bbox, vert, lab = synth.synth_batch(n, seed=3, neg_frac=0.0)
+    _, half = LB.neg_counts(int(LB.positive_count(bbox, lab).sum()), n)
+    rn = synth.synth_rand_neg_indices(n, half, seed=1).numpy()
+    lrn = synth.synth_rand_neg_indices(4 * n, 1, seed=2).reshape(4, n, 1).numpy()
+    bufs = {}
+
+    def step():
+        for p in P.values():
+            p.grad = None
+        outs = O.forward(kind, P, x)
+        res = O.loss_step(kind, outs, bbox.numpy(), vert.numpy(), lab.numpy(), rand_neg=rn, lm_rand_neg=lrn)
+        res['loss'].backward()
+        with torch.no_grad():
+            for k, p in P.items():
+                if p.grad is None:
+                    continue
+                newp, bufs[k] = O.sgd_step(p.detach(), p.grad, bufs.get(k), 1e-9)
+                p.copy_(newp)
+    step()                                    # warm-up
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        step()
+        it += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or it >= 50:
+            break
+    return {'value': round(n * it / el, 3), 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d training steps of %d synthetic 240x240 patches (%s, fp32, oracle/densebox_oracle.py), %.1f s'
+                      % (it, n, kind, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--kind', default='DenseBoxLMLOC', choices=list(FWD_GFLOP))
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
+    ap.add_argument('--batch', type=int, default=64, help='patches per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank, world, local = init_from_env()
+    assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node == --gpus'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    kind, n = args.kind, args.batch
+
+    net = getattr(D, kind)(synth.vgg19_standin(seed=0))
+    synth.fill_params_(net, 11)
+    net = net.to(dev).train()
+    net.compute_dtype = args.dtype
+    opt = SGD(net.parameters(), lr=1e-9, momentum=0.9, weight_decay=5e-8)       # DenseBox.py:2001-2004, :3841-3850
+    dp = DataParallel(net, opt)
+
+    # synthetic data, resident in HBM before the timed region; every rank draws its own shard of the global batch
+    x, bbox, vert, lab = synth.synth_batch(n, seed=100 + rank, neg_frac=0.1)
+    x = x.to(dev)
+    rs = np.random.RandomState(1234 + rank)
+    use_lab = lab if kind == 'DenseBoxLMLOC' else None
+    p_global = dp.global_positive_num(bbox, use_lab)                           # fixed labels -> fixed global count
+    _, half = LB.neg_counts(p_global, n * world)
+
+    def one_step():
+        # host RNG draws of the reference loop (DenseBox.py:2089-2094, :2133-2138) stay inside the step
+        rn = np.stack([rs.choice(3600, half, replace=False) for _ in range(n)]) if half else np.zeros((n, 0), np.int64)
+        lrn = rs.randint(0, 3600, size=(4, n, 1)) if kind != 'DenseBox' else None
+        return dp.step(x, bbox, vert, lab, rand_neg_indices=rn, lm_rand_neg_indices=lrn, positive_num_global=p_global)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.detach())
+    assert np.isfinite(loss_val), 'training step produced a non-finite loss'
+
+    out = None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = n * world * args.steps / dt
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (untimed extra steps)
+        eng = net.engine()
+        eng.profile = []
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        calls = eng.profile
+        eng.profile = None
+        fam = {}
+        for c in calls:
+            f = fam.setdefault(c['kernel'], {'us': 0.0, 'flops': 0.0, 'launches': 0})
+            f['us'] += c['start'].elapsed_time(c['end']) * 1e3
+            f['flops'] += c['flops']
+            f['launches'] += 1
+        dom = max(fam, key=lambda k: fam[k]['us'])
+        fd = fam[dom]
+        ach = fd['flops'] / (fd['us'] * 1e-6) / 1e12
+        peak = MFMA_PEAK_TF[args.dtype]
+        roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(ach / peak, 4), 'traffic': None,
+                'launches_per_step': fd['launches'] // 3, 'avg_launch_us': round(fd['us'] / fd['launches'], 2),
+                'families': {k: {'tflops': round(v['flops'] / (v['us'] * 1e-6) / 1e12, 1), 'us_per_step': round(v['us'] / 3, 1),
+                                 'launches_per_step': v['launches'] // 3} for k, v in fam.items()}}
+        out = {
+            'metric': 'training patches/sec (240x240)', 'value': round(value, 1), 'unit': 'patches/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'full training step (fwd + fused dense loss w/ hard-negative mining + bwd + grad '
+                                   'all-reduce + SGD) of %s on 240x240 patches' % kind,
+                       'net': kind, 'batch_per_gpu': n, 'global_batch': n * world, 'patch': '240x240',
+                       'parallelism': 'dp%d' % world, 'half_neg': half, 'loss': round(loss_val, 2)},
+            'step_tflops_per_gpu': round(n * STEP_GFLOP[kind] / (ms * 1e-3) / 1e3, 1),
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(kind, args.cpu_seconds)
+    barrier()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -21,4 +21,8 @@ class NetFunction(torch.autograd.Function):
             raise RuntimeError('densebox_amd: backward() after another forward() on the same module -- the '
                                'activations of this graph were overwritten (one graph in flight per module)')
         G = eng.backward_raw(dict(zip(ctx.names, grads)))
+        if eng.grad_sink is not None:
+            # data-parallel: gradients live in the reducer's flat buffer and are still being all-reduced;
+            # dist.DataParallel.step() attaches them as .grad once the collective is enqueued behind them
+            return (None, None) + (None,) * len(ctx.pnames)
         return (None, None) + tuple(G.get(n) for n in ctx.pnames)

@@ -1,0 +1,137 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, gradients all-reduced
+(SUM, no division -- the reference loss is a sum over the batch, DenseBox.py:2917) with RCCL over xGMI
+through torch.distributed (backend "nccl" is RCCL on ROCm), overlapped with the rest of backward.
+
+The reference has no multi-GPU path; ground truth = its single-process result on the
+concatenated global batch.  The one cross-sample coupling is ``neg_num = int(positive_num / N + 0.5)``
+(DenseBox.py:2074), which uses the positives of the WHOLE batch: ranks all-reduce one int64 over a
+gloo side group (host memory, no GPU sync) and pass the global batch size to the loss.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradReducer:
+    """Flat fp32 gradient buffer + bucketed asynchronous all-reduce.
+
+    ``order`` is the list of parameter names in the order backward produces them (deepest layers first), so each
+    bucket is a contiguous range of the flat buffer that can be sent while shallower layers are still computing.
+    """
+
+    def __init__(self, named_params, order, bucket_bytes=8 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        named = dict(named_params)
+        self.order = [n for n in order if n in named]
+        dev = next(iter(named.values())).device
+        total = sum(named[n].numel() for n in self.order)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.views, self.range = {}, {}
+        off = 0
+        for n in self.order:
+            p = named[n]
+            self.views[n] = self.flat[off:off + p.numel()].view_as(p)
+            self.range[n] = (off, off + p.numel())
+            off += p.numel()
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self._ready_hi = 0
+        self._sent_hi = 0
+        self._works = []
+
+    def grad_view(self, name):
+        return self.views[name]
+
+    def region(self, names):
+        """Contiguous flat range covering consecutive parameters (used for the fused heads' weight gradient)."""
+        lo, hi = self.range[names[0]][0], self.range[names[-1]][1]
+        assert hi - lo == sum(self.range[n][1] - self.range[n][0] for n in names), 'parameters are not adjacent'
+        return self.flat[lo:hi]
+
+    def begin(self):
+        self._ready_hi = self._sent_hi = 0
+        self._works = []
+
+    def ready(self, names):
+        """Called by the engine right after the kernels producing these gradients were enqueued."""
+        for n in names:
+            self._ready_hi = max(self._ready_hi, self.range[n][1])
+        if self.world > 1 and self._ready_hi - self._sent_hi >= self.bucket_elems:
+            self._send(self._ready_hi)
+
+    def _send(self, hi):
+        if hi > self._sent_hi:
+            # async_op=True: the RCCL stream waits for the compute stream's work enqueued so far, then runs concurrently
+            self._works.append(dist.all_reduce(self.flat[self._sent_hi:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True))
+            self._sent_hi = hi
+
+    def finish(self):
+        if self.world > 1:
+            self._send(self.flat.numel())
+            for w in self._works:
+                w.wait()          # makes the current stream wait for the collective; does not block the host
+        self._works = []
+
+
+class DataParallel:
+    """Wraps a densebox_amd network for data-parallel training.  ``step(...)`` = forward, fused loss with the global
+    mining constants, backward with overlapped all-reduce, fused SGD."""
+
+    def __init__(self, net, optimizer, bucket_bytes=8 << 20):
+        self.net, self.opt = net, optimizer
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.ctl = None
+        if self.world > 1:
+            for p in net.parameters():                       # replicate rank 0's weights
+                dist.broadcast(p.data, src=0)
+            # tiny host-side control collectives (positive counts) go over gloo: no device sync on the data path
+            self.ctl = dist.new_group(backend='gloo') if dist.get_backend() != 'gloo' else dist.group.WORLD
+        eng = net.engine()
+        self.reducer = GradReducer(net.named_parameters(), eng.grad_order(), bucket_bytes)
+        eng.grad_sink = self.reducer
+
+    def global_positive_num(self, bbox, labels=None):
+        from . import labels as LB
+        p = int(LB.positive_count(bbox, labels).sum())
+        if self.world > 1:
+            t = torch.tensor([p], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl)
+            p = int(t.item())
+        return p
+
+    def step(self, x, bbox, vertices=None, labels=None, rand_neg_indices=None, lm_rand_neg_indices=None,
+             positive_num_global=None, **loss_kw):
+        net = self.net
+        n_global = x.size(0) * self.world
+        if positive_num_global is None:
+            positive_num_global = self.global_positive_num(bbox, labels if net.KIND == 'DenseBoxLMLOC' else None)
+        self.opt.zero_grad(set_to_none=True)
+        self.reducer.begin()
+        outs = net(x)
+        loss = net.loss(outs, bbox, vertices, labels, rand_neg_indices, lm_rand_neg_indices,
+                        batch_global=n_global, positive_num_global=positive_num_global, **loss_kw)
+        loss.backward()
+        self.reducer.finish()
+        for name, p in net.named_parameters():
+            p.grad = self.reducer.views.get(name)          # None for conv3_3 (never executed)
+        self.opt.step()
+        return loss

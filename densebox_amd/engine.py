@@ -121,6 +121,22 @@ class Engine:
         self.wcache = {}       # (name, mode, dtype) -> (version key, packed tensor)
         self.bias_cache = {}
         self.last_plan = None
+        self.grad_sink = None      # optional dist.GradReducer: flat gradient views + readiness callbacks
+        self.profile = None        # list -> every conv / wgrad launch appends {kernel, flops, start, end} (HIP events)
+
+    def grad_order(self):
+        """Parameter names in the order backward_raw() finishes their gradients (deepest first)."""
+        heads = _HEADS[self.kind]
+        names = []
+        if self.kind != 'DenseBox':
+            for s_ in ('conv6_3_det', 'conv6_2_det', 'conv6_1_det'):
+                names += [s_ + '.weight', s_ + '.bias']
+        for s_, _ in heads:
+            names += ['conv5_2_%s.weight' % s_, 'conv5_2_%s.bias' % s_]
+        names += ['conv5_1_%s.weight' % s_ for s_, _ in heads] + ['conv5_1_%s.bias' % s_ for s_, _ in heads]
+        for s_, _, _ in reversed(_BACKBONE):
+            names += [s_ + '.weight', s_ + '.bias']
+        return names
 
     # ------------------------------------------------------------------ parameters
     def _param(self, name):
@@ -186,11 +202,25 @@ class Engine:
             self.plans = {key: p}      # keep one plan alive (shape changes re-plan)
         return p
 
-    def _conv(self, dt, x, y, wpk, bias, kh, kw, cpad, cin_pad, cout_pad, epi, gate=None, dropmask=None, dm_ld=0):
+    def _conv(self, dt, x, y, wpk, bias, kh, kw, cpad, cin_pad, cout_pad, epi, gate=None, dropmask=None, dm_ld=0,
+              alg_ci=None):
         d = ConvDesc(dt, kh, kw, cpad, cin_pad, cout_pad, epi)
+        prof = self.profile
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         check(self.L.dbx_conv_forward(C.byref(d), C.byref(x), ptr(wpk), ptr(bias), C.byref(y),
                                       C.byref(gate) if gate is not None else None,
                                       C.c_void_p(dropmask) if dropmask else None, dm_ld, stream_ptr()))
+        if prof is not None:
+            ev1.record()
+            # same tile rule as conv_igemm.hip::conv_forward_t; algorithmic FLOP = 2 * pixels * taps * Cin * Cout (real)
+            narrow = (cout_pad % 128 != 0) or y.c <= 64
+            small = cin_pad * _lib.ESIZE[dt] < 128
+            name = 'conv_igemm_kernel<%s,%s%s>' % (('f16', 'bf16', 'f32')[dt], '256,64,4,1' if narrow else '128,128,2,2',
+                                                  ',smallc' if small else '')
+            ci = alg_ci if alg_ci is not None else cin_pad
+            prof.append({'kernel': name, 'flops': 2.0 * y.n * y.h * y.w * kh * kw * ci * y.c, 'start': ev0, 'end': ev1})
 
     # ------------------------------------------------------------------ forward
     def forward(self, X):
@@ -229,7 +259,7 @@ class Engine:
             cin_pad = P.cin0 if cin == 3 else cin
             wp = self._w_fwd(dt, stem, cin_pad, max(64, cout))
             self._conv(dt, B[src].view(), dst_view if dst_view is not None else B[dst].view(), wp,
-                       self._bias([stem], max(64, cout)), 3, 3, 1, cin_pad, max(64, cout), RELU)
+                       self._bias([stem], max(64, cout)), 3, 3, 1, cin_pad, max(64, cout), RELU, alg_ci=cin)
 
         conv3('conv1_1_1', 'x0', 'a11', 3, 64)
         conv3('conv1_2_1', 'a11', 'a12', 64, 64)
@@ -276,7 +306,7 @@ class Engine:
             check(L.dbx_nchw_to_framed_ch(dt, ptr(outs['det']), 1, C.byref(rin), 4, s))
             check(L.dbx_maxpool2x2(dt, C.byref(rin), C.byref(B['rf_p'].view()), s))
             self._conv(dt, B['rf_p'].view(), B['rf_1'].view(), self._w_fwd(dt, 'conv6_1_det', P.crf, 64),
-                       self._bias(['conv6_1_det'], 64), 3, 3, 0, P.crf, 64, _lib.EPI_BIAS)
+                       self._bias(['conv6_1_det'], 64), 3, 3, 0, P.crf, 64, _lib.EPI_BIAS, alg_ci=5)
             self._conv(dt, B['rf_1'].view(), B['rf_2'].view(), self._w_fwd(dt, 'conv6_2_det', 64, 64),
                        self._bias(['conv6_2_det'], 64), 5, 5, 0, 64, 64, _lib.EPI_BIAS)
             check(L.dbx_upsample_bilinear(dt, C.byref(B['rf_2'].view()), C.byref(B['rf_u'].view()), s))
@@ -341,8 +371,17 @@ class Engine:
         need = self.L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dz), C.byref(x), kh, kw)
         if getattr(self, '_wg_scratch', None) is None or self._wg_scratch.numel() < need:
             self._wg_scratch = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=dw.device)
+        prof = self.profile
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         check(self.L.dbx_conv_wgrad(dt, C.byref(dz), C.byref(x), kh, kw, cpad, co, ci, ptr(dw), ptr(db),
                                     ptr(self._wg_scratch), accumulate, stream_ptr()))
+        if prof is not None:
+            ev1.record()
+            big = dz.c > 64 and x.c > 64
+            name = 'wgrad_kernel<%s,%s>' % (('f16', 'bf16', 'f32')[dt], '128,128' if big else '64,64')
+            prof.append({'kernel': name, 'flops': 2.0 * dz.n * dz.h * dz.w * kh * kw * ci * co, 'start': ev0, 'end': ev1})
 
     def backward_raw(self, grad_outs):
         """grad_outs: dict output-name -> fp32 NCHW tensor (or None).  Returns dict param-name -> fp32 gradient.
@@ -358,9 +397,11 @@ class Engine:
         h4, w4 = P.h4, P.w4
         G = {}
 
+        sink = self.grad_sink
+
         def new_grad(name):
             p = self._param(name)
-            g = torch.empty_like(p, dtype=torch.float32)
+            g = sink.grad_view(name) if sink is not None else torch.empty_like(p, dtype=torch.float32)
             G[name] = g
             return g
 
@@ -372,6 +413,8 @@ class Engine:
 
         def conv_bwd(stem, dz, x, kh, kw, cpad, co, ci):
             self._wgrad(dt, dz, x, kh, kw, cpad, co, ci, new_grad(stem + '.weight'), new_grad(stem + '.bias'))
+            if sink is not None:
+                sink.ready([stem + '.weight', stem + '.bias'])
 
         def dgrad(stem, src, dst, kh, kw, cpad, rows_pad, cin_pad, gate=None, epi=0, dropmask=None):
             wp = self._w_bwd(dt, stem, rows_pad, cin_pad)
@@ -408,12 +451,19 @@ class Engine:
             dgrad('conv5_2_' + stem, slot[stem], B['d_hid'].view(512 * i, 512), 1, 1, 0, 512, P.crf,
                   epi=_lib.EPI_DROPMASK if P.drop_active else 0,
                   dropmask=(P.mask_ptr + 512 * i) if P.drop_active else None)
-        dw1 = torch.empty((512 * nh, 768, 1, 1), dtype=torch.float32, device=dev)
-        db1 = torch.empty((512 * nh,), dtype=torch.float32, device=dev)
+        w1n = ['conv5_1_%s.weight' % st for st, _ in heads]
+        b1n = ['conv5_1_%s.bias' % st for st, _ in heads]
+        if sink is not None:           # the heads' conv5_1 gradients are adjacent in the flat buffer (grad_order)
+            dw1, db1 = sink.region(w1n).view(512 * nh, 768, 1, 1), sink.region(b1n)
+        else:
+            dw1 = torch.empty((512 * nh, 768, 1, 1), dtype=torch.float32, device=dev)
+            db1 = torch.empty((512 * nh,), dtype=torch.float32, device=dev)
         self._wgrad(dt, B['d_hid'].view(), B['fusion'].view(), 1, 1, 0, 512 * nh, 768, dw1, db1)
         for i, (stem, _) in enumerate(heads):
             G['conv5_1_%s.weight' % stem] = dw1[512 * i:512 * (i + 1)]
             G['conv5_1_%s.bias' % stem] = db1[512 * i:512 * (i + 1)]
+        if sink is not None:
+            sink.ready(w1n + b1n)
         w1t = self._w_heads1_bwd(dt)                          # [768 rows][512*nh]
         row_bytes = 512 * nh * _lib.ESIZE[dt]
         c34 = B['fusion'].view(512, 256)
