@@ -143,3 +143,29 @@ def test_training_step_low_precision(golden, dtype, cos_min):
         worst = min(worst, cos)
         assert cos >= cos_min, (name, cos)
     print('worst cosine', dtype, worst)
+
+
+def test_dataparallel_world1_equals_plain_autograd(golden):
+    """The data-parallel step (flat gradient buffer, readiness callbacks, global mining constants) with one rank must
+    reproduce the plain autograd path bit-for-bit (same kernels, same order)."""
+    from densebox_amd.dist import DataParallel
+    g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', 'f32')
+    outs, loss = _step(g, kind, net, n, x, 0)
+    loss.backward()
+    ref = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    opt = SGD(net.parameters(), lr=float(g['lr']))
+    dp = DataParallel(net, opt)
+    neg0 = g['s0_neg_idx_0']
+    half = neg0.shape[1] // 2
+    lm_rand = np.stack([g['s0_neg_idx_%d' % (1 + j)][:, 1:] for j in range(4)])
+    l2 = dp.step(x[:n].cuda(), g['bbox'][:n], g['vert'][:n], g['lab'][:n], rand_neg_indices=neg0[:, half:],
+                 lm_rand_neg_indices=lm_rand)
+    assert float(l2.detach()) == float(loss.detach())
+    for k, p in net.named_parameters():
+        if k in ref:
+            assert torch.equal(p.grad, ref[k]), k
+            assert not torch.equal(p.detach(), before[k]), k          # SGD moved it
+        else:
+            assert p.grad is None and torch.equal(p.detach(), before[k])   # conv3_3 untouched (DenseBox.py:193-195)
+    net.engine().grad_sink = None
