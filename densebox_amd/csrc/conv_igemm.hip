@@ -15,6 +15,7 @@
 // un-padded 3x3/5x5 refine convs, the Cin=3/5 layers (SMALLC: one 16-byte chunk per tap) and -- with
 // flipped/transposed packed weights -- every dgrad.
 #include "common.hpp"
+#include <stdlib.h>
 
 struct ConvArgs {
     const char* x;       // framed input, pointing at pixel (0,-pad,-pad) channel c_off
@@ -62,6 +63,67 @@ template <> struct Mma<float> {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, c, 0, 0, 0);
     }
 };
+
+template <typename T, int MI, int NI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI][MI], int m0, int n0, int wm_off, int wn_off, int lane) {
+    // ---- epilogue: lane holds couts cb + ni*16 + (l>>4)*4 + {0..3} of pixel mb + mi*16 + (l&15)
+    const int cb = n0 + wn_off + (lane >> 4) * 4;
+    const int mb = m0 + wm_off + (lane & 15);
+    const int epi = a.epi;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = mb + mi * 16;
+        if (m >= a.M) continue;
+        const int n = m / a.HoWo, r = m - n * a.HoWo;
+        const int oy = r / a.Wo, ox = r - oy * a.Wo;
+        const size_t ypix = ((size_t)(n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
+        const size_t gpix = ((size_t)(n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int c = cb + ni * 16;
+            if (c >= a.cout_valid) continue;
+            f32x4 v = acc[ni][mi];
+            if (epi & DBX_EPI_BIAS) {
+                const f32x4 b = *(const f32x4*)(a.bias + c);
+                v += b;
+            }
+            if (epi & DBX_EPI_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (epi & DBX_EPI_GATE) {
+                const T* g = (const T*)a.gate + gpix + c;
+                v.x = to_f32(g[0]) > 0.f ? v.x : 0.f; v.y = to_f32(g[1]) > 0.f ? v.y : 0.f;
+                v.z = to_f32(g[2]) > 0.f ? v.z : 0.f; v.w = to_f32(g[3]) > 0.f ? v.w : 0.f;
+            }
+            if (epi & DBX_EPI_DROPMASK) {
+                const unsigned int mk = *(const unsigned int*)(a.dropmask + (size_t)m * a.dm_ld + c);
+                v.x = (mk & 0xffu) ? v.x * 2.f : 0.f; v.y = (mk & 0xff00u) ? v.y * 2.f : 0.f;
+                v.z = (mk & 0xff0000u) ? v.z * 2.f : 0.f; v.w = (mk & 0xff000000u) ? v.w * 2.f : 0.f;
+            }
+            if (epi & DBX_EPI_F32_NCHW) {
+                float* o = (float*)a.y + ((size_t)n * a.cout_valid + c) * a.HoWo + r;
+                const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < a.cout_valid) {
+                        if (epi & DBX_EPI_ACCUM) o[(size_t)j * a.HoWo] += vv[j];
+                        else o[(size_t)j * a.HoWo] = vv[j];
+                    }
+            } else {
+                T* o = (T*)a.y + ypix + c;
+                if (epi & DBX_EPI_ACCUM) {
+                    v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]);
+                }
+                if constexpr (sizeof(T) == 2) {
+                    T p[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+                    *(u32x2*)o = *(const u32x2*)p;
+                } else {
+                    *(f32x4*)o = v;
+                }
+            }
+        }
+    }
+}
 
 template <typename T, int BM, int BN, int WM, int WN, bool SMALLC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
@@ -171,63 +233,124 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds couts cb + ni*16 + (l>>4)*4 + {0..3} of pixel mb + mi*16 + (l&15)
-    const int cb = n0 + wn * WTN + (lane >> 4) * 4;
-    const int mb = m0 + wm * WTM + (lane & 15);
-    const int epi = a.epi;
+    conv_epilogue<T, MI, NI>(a, acc, m0, n0, wm * WTM, wn * WTN, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ v2: LDS-DMA ring
+// 512 threads = 8 waves as 4(M) x (BN/64)(N)... each wave still owns a 64x64 output tile.  The A (pixel) and B (weight)
+// tiles of one 128-byte K step go global -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no ds_write
+// pass) into a 3-stage ring; loads run two K steps ahead of the MFMAs and are retired with a COUNTED vmcnt, one raw
+// s_barrier per step:
+//      wait(my loads of step ks) ; barrier ; issue loads of step ks+2 into the stage read at ks-1 ; MFMAs of step ks
+// The LDS image of a wave-instruction is lane-linear (8 rows x 128 B), so the XOR swizzle that keeps ds_read_b128
+// conflict-free is applied to the per-lane SOURCE address (logical chunk = physical chunk ^ ((row>>1)&7)).
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
+    constexpr int WN = BN / 64, WM = 8 / WN;               // 8 waves
+    constexpr int WTM = BM / WM, WTN = 64;                 // 64x64 per wave (32x64 for the 64-cout tile)
+    constexpr int MI = WTM / 16, NI = 4;
+    constexpr int ES = sizeof(T);
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int A_PER_WAVE = BM / 8 / 8;                 // 1-KiB pieces (8 rows) of the A tile per wave per step
+    constexpr int B_PER_WAVE = BN / 8 / 8;
+    constexpr int LOADS = A_PER_WAVE + B_PER_WAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    int bid = blockIdx.x;
+    {
+        const int q = a.nblocks >> 3, r = a.nblocks & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tile_m = bid / a.ntile_n, tile_n = bid - tile_m * a.ntile_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-lane source pointers: piece p of this wave covers tile rows 8*(wave*PER_WAVE + p) + (lane>>3)
+    const int lr = lane >> 3, lc = lane & 7;
+    const char* arow[A_PER_WAVE];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-        const int m = mb + mi * 16;
-        if (m >= a.M) continue;
+    for (int p = 0; p < A_PER_WAVE; ++p) {
+        const int row = 8 * (wave * A_PER_WAVE + p) + lr;
+        int m = m0 + row;
+        m = m < a.M ? m : a.M - 1;
         const int n = m / a.HoWo, r = m - n * a.HoWo;
         const int oy = r / a.Wo, ox = r - oy * a.Wo;
-        const size_t ypix = ((size_t)(n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
-        const size_t gpix = ((size_t)(n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int c = cb + ni * 16;
-            if (c >= a.cout_valid) continue;
-            f32x4 v = acc[ni][mi];
-            if (epi & DBX_EPI_BIAS) {
-                const f32x4 b = *(const f32x4*)(a.bias + c);
-                v += b;
-            }
-            if (epi & DBX_EPI_RELU) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            if (epi & DBX_EPI_GATE) {
-                const T* g = (const T*)a.gate + gpix + c;
-                v.x = to_f32(g[0]) > 0.f ? v.x : 0.f; v.y = to_f32(g[1]) > 0.f ? v.y : 0.f;
-                v.z = to_f32(g[2]) > 0.f ? v.z : 0.f; v.w = to_f32(g[3]) > 0.f ? v.w : 0.f;
-            }
-            if (epi & DBX_EPI_DROPMASK) {
-                const unsigned int mk = *(const unsigned int*)(a.dropmask + (size_t)m * a.dm_ld + c);
-                v.x = (mk & 0xffu) ? v.x * 2.f : 0.f; v.y = (mk & 0xff00u) ? v.y * 2.f : 0.f;
-                v.z = (mk & 0xff0000u) ? v.z * 2.f : 0.f; v.w = (mk & 0xff000000u) ? v.w * 2.f : 0.f;
-            }
-            if (epi & DBX_EPI_F32_NCHW) {
-                float* o = (float*)a.y + ((size_t)n * a.cout_valid + c) * a.HoWo + r;
-                const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c + j < a.cout_valid) {
-                        if (epi & DBX_EPI_ACCUM) o[(size_t)j * a.HoWo] += vv[j];
-                        else o[(size_t)j * a.HoWo] = vv[j];
-                    }
-            } else {
-                T* o = (T*)a.y + ypix + c;
-                if (epi & DBX_EPI_ACCUM) {
-                    v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]);
-                }
-                if constexpr (sizeof(T) == 2) {
-                    T p[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
-                    *(u32x2*)o = *(const u32x2*)p;
-                } else {
-                    *(f32x4*)o = v;
-                }
-            }
-        }
+        const int chunk = lc ^ ((row >> 1) & 7);
+        arow[p] = a.x + ((size_t)(n * a.x_hp + oy + a.x_org) * a.x_wp + (ox + a.x_org)) * (size_t)a.x_ld * ES + chunk * 16;
     }
+    const char* brow[B_PER_WAVE];
+#pragma unroll
+    for (int p = 0; p < B_PER_WAVE; ++p) {
+        const int row = 8 * (wave * B_PER_WAVE + p) + lr;
+        const int chunk = lc ^ ((row >> 1) & 7);
+        brow[p] = a.w + (size_t)(n0 + row) * a.ktot_bytes + chunk * 16;
+    }
+    const int pix_bytes = a.x_ld * ES;
+
+    // issue-side K bookkeeping (uniform): byte offset of the current tap and position inside its channel run
+    int is_within = 0, is_kx = 0, is_tapoff = 0, is_k = 0;
+    auto issue = [&](int stage) {
+        const int aoff = is_tapoff + is_within * 16;
+        char* sbase = smem + stage * STAGE;
+#pragma unroll
+        for (int p = 0; p < A_PER_WAVE; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(arow[p] + aoff),
+                                             (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + p) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < B_PER_WAVE; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow[p] + is_k * 128),
+                                             (__attribute__((address_space(3))) void*)(sbase + BM * 128 + (wave * B_PER_WAVE + p) * 1024), 16, 0, 0);
+        ++is_k;
+        is_within += 8;
+        if (is_within == a.cpt) {                           // next tap
+            is_within = 0;
+            if (++is_kx == a.kw) { is_kx = 0; is_tapoff += (a.x_wp - a.kw + 1) * pix_bytes; }
+            else is_tapoff += pix_bytes;
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15;
+    const int c0sw = ((lane >> 4) ^ ((lane >> 1) & 7)) << 4;
+    const int rd_a = (wm * WTM + fr) * 128;
+    const int rd_b = BM * 128 + (wn * WTN + fr) * 128;
+
+    const int nk = a.ksteps;
+    issue(0);
+    if (nk > 1) issue(1);
+    int stage = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (ks + 2 < nk) issue(stage >= 1 ? stage - 1 : 2);  // (ks+2)%3 == (ks-1)%3: the stage everyone just finished reading
+        const char* Ab = smem + stage * STAGE + rd_a;
+        const char* Bb = smem + stage * STAGE + rd_b;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int co = c0sw ^ (kk << 6);
+            u32x4 wf[NI], xf[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const u32x4*)(Bb + ni * 16 * 128 + co);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const u32x4*)(Ab + mi * 16 * 128 + co);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) Mma<T>::run(wf[ni], xf[mi], acc[ni][mi]);
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    conv_epilogue<T, MI, NI>(a, acc, m0, n0, wm * WTM, wn * WTN, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -253,6 +376,25 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, SMALLC>), dim3(a.nblocks), dim3(256), smem, s, a);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
+}
+
+template <typename T, int BM, int BN>
+static int launch_conv_dma(const ConvArgs& a, hipStream_t s) {
+    constexpr int smem = 3 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DBX_HIP(hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<T, BM, BN>), dim3(a.nblocks), dim3(512), smem, s, a);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+static int conv_variant() {          // DBX_CONV_VARIANT=1 forces the register-staged v1 kernel everywhere (A/B testing)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DBX_CONV_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
 }
 
 template <typename T>
@@ -294,6 +436,18 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.epi = d->epilogue; a.dm_ld = dm_ld;
     DBX_REQUIRE(a.M > 0 && (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < (int64_t)1 << 40, "conv: empty or oversized input");
 
+    // LDS-DMA ring kernel: any non-small-Cin layer (f16/bf16/f32 alike); 256x128 tiles, 256x64 when the layer has 64 couts
+    if (!smallc && conv_variant() != 1 && a.ksteps >= 2) {
+        const bool n64 = (d->cout_pad % 128 != 0) || y->c <= 64;
+        if (n64) {
+            a.ntile_n = y->c <= 64 ? 1 : d->cout_pad / 64;
+            a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
+            return launch_conv_dma<T, 256, 64>(a, s);
+        }
+        a.ntile_n = (y->c + 127) / 128;
+        a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
+        return launch_conv_dma<T, 256, 128>(a, s);
+    }
     // tile choice: couts are tiled by 128 unless the layer has 64 (or the result is tiny, e.g. the 512->k heads)
     const bool narrow = (d->cout_pad % 128 != 0) || y->c <= 64;
     if (narrow) {
