@@ -13,6 +13,7 @@
 // slabs in fixed order (deterministic) and scatters into the fp32 OIHW gradient.  Workgroups of ci-tile 0 / tap 0
 // also accumulate the bias gradient db[co] = sum_q dz[q][co] from the tiles they stream anyway.
 #include "common.hpp"
+#include <stdlib.h>
 
 typedef short short4v __attribute__((ext_vector_type(4)));
 
@@ -205,6 +206,156 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ 3x3, all taps per workgroup
+// For layers with few channels (Cout, Cin <= 128 at 240x240 / 120x120) the per-tap tiling above is bound by refilling
+// LDS: every tap re-reads the same dz rows and a shifted copy of the same x rows (32 FLOP per byte filled).  Here one
+// workgroup owns a 64(co) x 64(ci) tile for ALL nine taps: per K step it stages 32 rows of dz once and three row bands
+// of x (one per ky, 32+2 rows so that the three kx shifts are just +0/+1/+2 row offsets of the transpose reads), and
+// issues 9 x 4 MFMAs per wave per barrier.  4.3x fewer bytes through L2/LDS per FLOP; conv1_1's dz is streamed once
+// instead of nine times.  16-bit types only (the f32 parity path keeps the generic kernel).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit tiles");
+    constexpr int R = 32, BAND = R + 2;
+    constexpr int A_BYTES = R * 128, B_BYTES = 3 * BAND * 128;       // 64 channels x 2 B per row
+    constexpr int B_CHUNKS = 3 * BAND * 8;                            // 816 16-byte chunks
+    constexpr int LD_B = (B_CHUNKS + 255) / 256;                      // 4 per thread (last one partial)
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+    char* As = smem;
+    char* Bs = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                           // wave tile 32(co) x 32(ci)
+    const int tile_ci = blockIdx.x % a.tiles_ci, tile_co = blockIdx.x / a.tiles_ci;
+    const int split = blockIdx.y;
+    const long long q0 = (long long)split * a.rows_per_split;
+    long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
+    const int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
+    const bool do_bias = (tile_ci == 0 && a.bpartial != nullptr);
+
+    // ---- loaders: dz 32 rows x 8 chunks (1 per thread); x 3 bands x 34 rows x 8 chunks
+    const int ca = tid & 7, ra = tid >> 3;
+    const bool a_ok = (tile_co * 128 + ca * 16) < a.dz_c * 2;
+    const char* ap = a.dz + ((q0 + ra) * a.dz_ld + tile_co * 64) * 2LL + ca * 16;
+    const long long a_row = (long long)a.dz_ld * 2, b_row = (long long)a.x_ld * 2;
+    const char* bp[LD_B];
+    int b_lds[LD_B];
+    bool b_ok[LD_B];
+#pragma unroll
+    for (int i = 0; i < LD_B; ++i) {
+        const int c = tid + 256 * i;                                  // chunk id
+        const int row = c >> 3, cb = c & 7;                           // LDS row (band*34 + j), chunk in row
+        const int band = row / BAND, j = row - band * BAND;
+        b_ok[i] = c < B_CHUNKS && (tile_ci * 128 + cb * 16) < a.x_c * 2;
+        const long long grow = q0 + (long long)(band + a.shift0) * a.wp + a.shift0 + j;
+        bp[i] = a.x + (grow * a.x_ld + tile_ci * 64) * 2LL + cb * 16;
+        b_lds[i] = c < B_CHUNKS ? swz16<64>(row, cb * 16) : 0;
+    }
+    u32x4 areg, breg[LD_B];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto gload = [&](int s) {
+        areg = a_ok ? *(const u32x4*)(ap + (long long)s * R * a_row) : zero4;
+#pragma unroll
+        for (int i = 0; i < LD_B; ++i) breg[i] = b_ok[i] ? *(const u32x4*)(bp[i] + (long long)s * R * b_row) : zero4;
+    };
+    auto lstore = [&](int buf) {
+        *(u32x4*)(As + buf * A_BYTES + swz16<64>(ra, ca * 16)) = areg;
+#pragma unroll
+        for (int i = 0; i < LD_B; ++i)
+            if (tid + 256 * i < B_CHUNKS) *(u32x4*)(Bs + buf * B_BYTES + b_lds[i]) = breg[i];
+    };
+
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[t][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    auto bias_acc = [&]() {
+        const T* e = (const T*)&areg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += to_f32(e[j]);
+    };
+
+    if (nsteps > 0) { gload(0); if (do_bias) bias_acc(); lstore(0); }
+    __syncthreads();
+    const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        const char* Ab = As + buf * A_BYTES;
+        const char* Bb = Bs + buf * B_BYTES;
+        u32x4 af[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int cbyte = (wm * 32 + mi * 16) * 2 + csub;
+            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Ab + swz16<64>(8 * g + rsub, cbyte)));
+            const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Ab + swz16<64>(8 * g + 4 + rsub, cbyte)));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+            af[mi] = (u32x4){l2.x, l2.y, h2.x, h2.y};
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t - ky * 3;
+            const int rbase = ky * BAND + kx;                          // band row of q-row 0 for this tap
+            u32x4 bf[2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int cbyte = (wn * 32 + ni * 16) * 2 + csub;
+                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Bb + swz16<64>(rbase + 8 * g + rsub, cbyte)));
+                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Bb + swz16<64>(rbase + 8 * g + 4 + rsub, cbyte)));
+                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                bf[ni] = (u32x4){l2.x, l2.y, h2.x, h2.y};
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    if constexpr (DType<T>::id == DBX_F16)
+                        acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mi]), __builtin_bit_cast(f16x8, bf[ni]), acc[t][mi][ni], 0, 0, 0);
+                    else
+                        acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[ni]), acc[t][mi][ni], 0, 0, 0);
+                }
+        }
+        if (s + 1 < nsteps) { if (do_bias) bias_acc(); lstore(buf ^ 1); }
+        __syncthreads();
+    }
+
+    {
+        float* P = a.partial + (((long long)split * a.co_pad) * 9) * a.ci_pad;
+        const int co_b = tile_co * 64 + wm * 32 + (lane >> 4) * 4;
+        const int ci_b = tile_ci * 64 + wn * 32 + (lane & 15);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float v[4] = {acc[t][mi][ni].x, acc[t][mi][ni].y, acc[t][mi][ni].z, acc[t][mi][ni].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) P[((long long)(co_b + mi * 16 + r) * 9 + t) * a.ci_pad + ci_b + ni * 16] = v[r];
+                }
+    }
+    if (do_bias) {
+        __syncthreads();
+        float* red = (float*)smem;                       // [32 rows][64]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[ra * 64 + ca * 8 + j] = bsum[j];
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+            for (int r = 0; r < 32; ++r) sum += red[r * 64 + tid];
+            a.bpartial[(long long)split * a.co_pad + tile_co * 64 + tid] = sum;
+        }
+    }
+}
+
 // dw[co][ci][tap] = sum_s partial[s][co][tap][ci]   (fixed summation order), db[co] = sum_s bpartial[s][co]
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits, int co,
                                     int ci, int taps, int co_pad, int ci_pad, float* __restrict__ dw, float* __restrict__ db,
@@ -231,19 +382,28 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split; long long Q; };
+struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps; long long Q; };
 
-static WgradPlan wgrad_plan(const dbx_view* dz, const dbx_view* x, int kh, int kw) {
+static int wgrad_variant() {          // DBX_WGRAD_VARIANT=1: generic per-tap kernel everywhere (A/B testing)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DBX_WGRAD_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, int kh, int kw) {
     WgradPlan p;
     p.bmc = dz->c > 64 ? 128 : 64;
     p.bnc = x->c > 64 ? 128 : 64;
     if (p.bmc != p.bnc) { p.bmc = 64; p.bnc = 64; }        // compiled tile shapes: 128x128 and 64x64
+    // few-channel 3x3 layers: one workgroup accumulates all nine taps of a 64x64 tile
+    p.alltaps = (dtype != DBX_F32 && kh == 3 && kw == 3 && wgrad_variant() != 1 && ((dz->c <= 128 && x->c <= 128) || wgrad_variant() == 2)) ? 1 : 0;
+    if (p.alltaps) { p.bmc = 64; p.bnc = 64; }
     p.co_pad = (dz->c + p.bmc - 1) / p.bmc * p.bmc;
     p.ci_pad = (x->c + p.bnc - 1) / p.bnc * p.bnc;
     p.tiles_co = p.co_pad / p.bmc; p.tiles_ci = p.ci_pad / p.bnc;
     p.taps = kh * kw;
     p.Q = (long long)dz->n * (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad);
-    const long long tiles = (long long)p.tiles_co * p.tiles_ci * p.taps;
+    const long long tiles = (long long)p.tiles_co * p.tiles_ci * (p.alltaps ? 1 : p.taps);
     const long long steps = (p.Q + 31) / 32;
     long long splits = (1024 + tiles - 1) / tiles;            // aim for ~4 workgroups per CU
     const long long max_by_steps = steps / 16 > 0 ? steps / 16 : 1;   // at least 16 K-steps (512 rows) per split
@@ -257,8 +417,7 @@ static WgradPlan wgrad_plan(const dbx_view* dz, const dbx_view* x, int kh, int k
 }
 
 extern "C" int64_t dbx_conv_wgrad_scratch_bytes(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw) {
-    (void)dtype;
-    const WgradPlan p = wgrad_plan(dz, x, kh, kw);
+    const WgradPlan p = wgrad_plan(dtype, dz, x, kh, kw);
     return ((int64_t)p.splits * p.co_pad * p.taps * p.ci_pad + (int64_t)p.splits * p.co_pad) * 4 + 256;
 }
 
@@ -273,7 +432,7 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     DBX_REQUIRE(((size_t)dz->ptr % 16) == 0 && ((size_t)x->ptr % 16) == 0 && (dz->ld * ES) % 16 == 0 && (x->ld * ES) % 16 == 0 &&
                     (dz->c_off * ES) % 16 == 0 && (x->c_off * ES) % 16 == 0 && (dz->c * ES) % 16 == 0 && (x->c * ES) % 16 == 0,
                 "wgrad: 16-byte alignment");
-    const WgradPlan p = wgrad_plan(dz, x, kh, kw);
+    const WgradPlan p = wgrad_plan(DType<T>::id, dz, x, kh, kw);
     WgradArgs a;
     a.dz = (const char*)dz->ptr + (size_t)dz->c_off * ES;
     a.x = (const char*)x->ptr + (size_t)x->c_off * ES;
@@ -283,9 +442,14 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.co_pad = p.co_pad; a.ci_pad = p.ci_pad; a.taps = p.taps; a.kw = kw; a.wp = x->w + 2 * x->pad;
     a.shift0 = x->pad - dz->pad - cpad;
     a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci; a.rows_per_split = p.rows_per_split;
-    const dim3 grid(p.tiles_co * p.tiles_ci * p.taps, p.splits);
-    if (p.bmc == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, dim3(256), 0, s, a);
+    if (p.alltaps) {
+        if constexpr (sizeof(T) == 2)
+            hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci, p.splits), dim3(256), 0, s, a);
+    } else {
+        const dim3 grid(p.tiles_co * p.tiles_ci * p.taps, p.splits);
+        if (p.bmc == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, dim3(256), 0, s, a);
+    }
     DBX_LAUNCH_CHECK();
     const long long total = (long long)co * p.taps * ci + co;
     int blocks = (int)((total + 255) / 256); blocks = blocks > 4096 ? 4096 : blocks;

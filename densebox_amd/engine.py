@@ -217,8 +217,11 @@ class Engine:
             # same tile rule as conv_igemm.hip::conv_forward_t; algorithmic FLOP = 2 * pixels * taps * Cin * Cout (real)
             narrow = (cout_pad % 128 != 0) or y.c <= 64
             small = cin_pad * _lib.ESIZE[dt] < 128
-            name = 'conv_igemm_kernel<%s,%s%s>' % (('f16', 'bf16', 'f32')[dt], '256,64,4,1' if narrow else '128,128,2,2',
-                                                  ',smallc' if small else '')
+            tn = ('f16', 'bf16', 'f32')[dt]
+            if small:
+                name = 'conv_igemm_kernel<%s,%s,smallc>' % (tn, '256,64,4,1' if narrow else '128,128,2,2')
+            else:
+                name = 'conv_igemm_dma_kernel<%s,%s>' % (tn, '256,64' if narrow else '256,128')
             ci = alg_ci if alg_ci is not None else cin_pad
             prof.append({'kernel': name, 'flops': 2.0 * y.n * y.h * y.w * kh * kw * ci * y.c, 'start': ev0, 'end': ev1})
 
@@ -380,7 +383,11 @@ class Engine:
         if prof is not None:
             ev1.record()
             big = dz.c > 64 and x.c > 64
-            name = 'wgrad_kernel<%s,%s>' % (('f16', 'bf16', 'f32')[dt], '128,128' if big else '64,64')
+            tn = ('f16', 'bf16', 'f32')[dt]
+            if dt != _lib.F32 and kh == 3 and kw == 3 and dz.c <= 128 and x.c <= 128:
+                name = 'wgrad3x3_kernel<%s>' % tn
+            else:
+                name = 'wgrad_kernel<%s,%s>' % (tn, '128,128' if big else '64,64')
             prof.append({'kernel': name, 'flops': 2.0 * dz.n * dz.h * dz.w * kh * kw * ci * co, 'start': ev0, 'end': ev1})
 
     def backward_raw(self, grad_outs):

@@ -1,0 +1,108 @@
+"""Kernel-level GPU parity through the C ABI: conv forward / weight-gradient kernels in f16 and bf16 against a torch
+fp32 computation on the SAME rounded operands (so the only difference is fp32 summation order), for every tile/variant
+the dispatcher can pick (register-staged v1, LDS-DMA ring, small-Cin, per-tap wgrad, all-taps 3x3 wgrad)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from densebox_amd import _lib
+from densebox_amd._lib import View, ConvDesc, check, ptr, stream_ptr
+
+pytestmark = pytest.mark.gpu
+TDT = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}
+
+
+def framed(x_nchw, pad, tdt):
+    """NCHW fp32 -> zero-framed NHWC tensor (with zero guard bands) + the View."""
+    n, c, h, w = x_nchw.shape
+    hp, wp = h + 2 * pad, w + 2 * pad
+    guard = 8 * wp * c
+    flat = torch.zeros(2 * guard + n * hp * wp * c, dtype=tdt, device='cuda')
+    t = flat[guard:guard + n * hp * wp * c].view(n, hp, wp, c)
+    t[:, pad:pad + h, pad:pad + w] = x_nchw.permute(0, 2, 3, 1).to(tdt)
+    return flat, t, View(C.c_void_p(t.data_ptr()), n, h, w, pad, c, 0, c)
+
+
+def pack(L, dt, w, cin_pad, cout_pad, mode=0):
+    d = ConvDesc(dt, w.shape[2], w.shape[3], 0, cin_pad, cout_pad, 0)
+    out = torch.zeros(L.dbx_conv_packed_elems(C.byref(d)) * _lib.ESIZE[dt], dtype=torch.uint8, device='cuda')
+    check(L.dbx_pack_weight(dt, mode, ptr(w), w.shape[0], w.shape[1], w.shape[2], w.shape[3], ptr(out), cout_pad, cin_pad, 0, 0,
+                            stream_ptr()))
+    return out
+
+
+CONV_CASES = [  # n, h, w, cin, cout, k, pad
+    (2, 20, 28, 64, 64, 3, 1), (3, 17, 23, 128, 256, 3, 1), (1, 30, 30, 512, 512, 3, 1), (2, 15, 15, 768, 1024, 1, 0),
+    (2, 14, 14, 64, 64, 5, 0), (1, 33, 9, 256, 128, 3, 1),
+]
+
+
+@pytest.mark.parametrize('variant', ['dma', 'v1'])
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_forward_kernel(case, dtn, variant, monkeypatch):
+    if variant == 'v1':
+        pytest.skip('v1/v2 selection is per process (env DBX_CONV_VARIANT); v1 is covered by the f32 + small-Cin paths')
+    n, h, w, ci, co, k, pad = case
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    g = torch.Generator(device='cpu').manual_seed(hash(case) % 1000)
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, k, k, generator=g) * (2.0 / (ci * k * k)) ** 0.5).cuda()
+    b = torch.randn(co, generator=g).cuda()
+    xr, wr = x.to(tdt).float(), wt.to(tdt).float()
+    ref = F.relu(F.conv2d(xr, wr, b, padding=pad))
+    ho, wo = ref.shape[2], ref.shape[3]
+    fx, tx, xv = framed(x, 1, tdt)            # keep the tensors alive: the Views only carry raw pointers
+    fy, ty, yv = framed(torch.zeros(n, co, ho, wo), 1, tdt)
+    d = ConvDesc(dt, k, k, pad, ci, co, _lib.EPI_BIAS | _lib.EPI_RELU)
+    check(L.dbx_conv_forward(C.byref(d), C.byref(xv), ptr(pack(L, dt, wt, ci, co)), ptr(b), C.byref(yv), None, None, 0, stream_ptr()))
+    got = ty[:, 1:1 + ho, 1:1 + wo].permute(0, 3, 1, 2).float()
+    tol = (2e-2 if dtn == 'bf16' else 3e-3)          # output rounding to the 16-bit type dominates
+    assert torch.allclose(got, ref, rtol=tol, atol=tol), (got - ref).abs().max().item()
+    # the zero frame must be untouched
+    assert float(ty[:, 0].abs().sum()) == 0 and float(ty[:, :, 0].abs().sum()) == 0
+    assert float(ty[:, -1].abs().sum()) == 0 and float(ty[:, :, -1].abs().sum()) == 0
+
+
+WG_CASES = [  # n, h, w, cin (view), cin real, cout, k, pad
+    (2, 20, 28, 64, 64, 64, 3, 1), (2, 24, 24, 8, 3, 64, 3, 1), (3, 17, 23, 64, 64, 128, 3, 1), (2, 12, 12, 128, 128, 128, 3, 1),
+    (1, 30, 30, 256, 256, 512, 3, 1), (2, 15, 15, 768, 768, 512, 1, 0), (2, 16, 16, 512, 512, 8, 1, 0),
+]
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', WG_CASES)
+def test_conv_wgrad_kernel(case, dtn):
+    n, h, w, civ, ci, co, k, pad = case
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    g = torch.Generator(device='cpu').manual_seed(hash(case) % 1000)
+    x = torch.zeros(n, civ, h, w)
+    x[:, :ci] = torch.randn(n, ci, h, w, generator=g)
+    cov = max(co, 8)
+    dz = torch.zeros(n, cov, h, w)
+    dz[:, :co] = torch.randn(n, co, h, w, generator=g)
+    x, dz = x.cuda(), dz.cuda()
+    xr = x.to(tdt).float().requires_grad_(False)
+    dzr = dz.to(tdt).float()
+    wref = torch.zeros(co, ci, k, k, device='cuda', requires_grad=True)
+    bref = torch.zeros(co, device='cuda', requires_grad=True)
+    out = F.conv2d(xr[:, :ci], wref, bref, padding=pad)
+    out.backward(dzr[:, :co])
+    fx, tx, xv = framed(x, 1, tdt)            # keep the tensors alive: the Views only carry raw pointers
+    fz, tz, dzv = framed(dz, 1, tdt)
+    dw = torch.empty(co, ci, k, k, device='cuda')
+    db = torch.empty(co, device='cuda')
+    sc = torch.empty(L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dzv), C.byref(xv), k, k), dtype=torch.uint8, device='cuda')
+    check(L.dbx_conv_wgrad(dt, C.byref(dzv), C.byref(xv), k, k, pad, co, ci, ptr(dw), ptr(db), ptr(sc), 0, stream_ptr()))
+    scale = wref.grad.abs().max().item()
+    assert (dw - wref.grad).abs().max().item() <= 2e-4 * scale + 1e-4, ((dw - wref.grad).abs().max().item(), scale)
+    assert torch.allclose(db, bref.grad, rtol=1e-4, atol=1e-3)
+    # accumulate flag
+    check(L.dbx_conv_wgrad(dt, C.byref(dzv), C.byref(xv), k, k, pad, co, ci, ptr(dw), ptr(db), ptr(sc), 1, stream_ptr()))
+    assert (dw - 2 * wref.grad).abs().max().item() <= 4e-4 * scale + 2e-4
