@@ -137,31 +137,37 @@ extern "C" int dbx_maxpool2x2(int32_t dtype, const dbx_view* x, const dbx_view* 
     DBX_DISPATCH_DTYPE(dtype, maxpool_t, x, y, (hipStream_t)stream);
 }
 
-// backward: one lane per (pre-pool pixel, channel group).  The arg-max is the FIRST window element equal to the
-// maximum in (0,0),(0,1),(1,0),(1,1) order -- ATen's max_pool2d keeps the earlier element on ties.
+// backward: one lane per (2x2 window, channel group): every byte of x, dy and dx moves exactly once.  The arg-max is
+// the FIRST window element equal to the maximum in (0,0),(0,1),(1,0),(1,1) order -- ATen's max_pool2d keeps the earlier
+// element on ties.  Windows beyond the pooled extent (odd H/W, floor mode) cover pixels no output saw: gradient 0.
 template <typename T>
 __global__ void maxpool_bwd_kernel(FrameGeo x, FrameGeo dy, FrameGeo dx, int ph, int pw, int accumulate, int relu_gate) {
     constexpr int V = Vec<T>::N;
     const int cg = x.c / V;
-    const int64_t total = (int64_t)x.n * x.h * x.w * cg;
+    const int wh = (x.h + 1) >> 1, ww = (x.w + 1) >> 1;               // windows incl. the ragged last row/column
+    const int64_t total = (int64_t)x.n * wh * ww * cg;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int g = (int)(i % cg);
-        const int px = (int)((i / cg) % x.w);
-        const int py = (int)((i / ((int64_t)cg * x.w)) % x.h);
-        const int n = (int)(i / ((int64_t)cg * x.w * x.h));
-        float o[V];
+        const int wx = (int)((i / cg) % ww);
+        const int wy = (int)((i / ((int64_t)cg * ww)) % wh);
+        const int n = (int)(i / ((int64_t)cg * ww * wh));
+        const bool covered = wy < ph && wx < pw;
+        const size_t p00 = geo_pix(x, n, 2 * wy, 2 * wx) + g * V;
+        const size_t d00 = geo_pix(dx, n, 2 * wy, 2 * wx) + g * V;
+        const bool has_x1 = 2 * wx + 1 < x.w, has_y1 = 2 * wy + 1 < x.h;
+        float o[4][V];
 #pragma unroll
-        for (int j = 0; j < V; ++j) o[j] = 0.f;
-        const int wy = py >> 1, wx = px >> 1;
-        if (wy < ph && wx < pw) {
-            const T* p = (const T*)x.base + geo_pix(x, n, 2 * wy, 2 * wx) + g * V;
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < V; ++j) o[k][j] = 0.f;
+        if (covered) {
             float q[4][V], gd[V];
+            const T* p = (const T*)x.base + p00;
             load_vec<T>(p, q[0]);
             load_vec<T>(p + x.ld, q[1]);
             load_vec<T>(p + (size_t)x.wp * x.ld, q[2]);
             load_vec<T>(p + (size_t)x.wp * x.ld + x.ld, q[3]);
             load_vec<T>((const T*)dy.base + geo_pix(dy, n, wy, wx) + g * V, gd);
-            const int me = ((py & 1) << 1) | (px & 1);
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 int arg = 0;
@@ -169,19 +175,25 @@ __global__ void maxpool_bwd_kernel(FrameGeo x, FrameGeo dy, FrameGeo dx, int ph,
 #pragma unroll
                 for (int k = 1; k < 4; ++k)
                     if (q[k][j] > m) { m = q[k][j]; arg = k; }
-                float v = arg == me ? gd[j] : 0.f;
-                if (relu_gate && !(q[me][j] > 0.f)) v = 0.f;
-                o[j] = v;
+                float v = gd[j];
+                if (relu_gate && !(m > 0.f)) v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k][j] = (k == arg) ? v : 0.f;
             }
         }
-        T* dst = (T*)dx.base + geo_pix(dx, n, py, px) + g * V;
-        if (accumulate) {
-            float old[V];
-            load_vec<T>(dst, old);
 #pragma unroll
-            for (int j = 0; j < V; ++j) o[j] += old[j];
+        for (int k = 0; k < 4; ++k) {
+            if ((k & 1) && !has_x1) continue;
+            if ((k >> 1) && !has_y1) continue;
+            T* dst = (T*)dx.base + d00 + (size_t)(k >> 1) * dx.wp * dx.ld + (size_t)(k & 1) * dx.ld;
+            if (accumulate) {
+                float old[V];
+                load_vec<T>(dst, old);
+#pragma unroll
+                for (int j = 0; j < V; ++j) o[k][j] += old[j];
+            }
+            store_vec<T>(dst, o[k]);
         }
-        store_vec<T>(dst, o);
     }
 }
 template <typename T>
@@ -189,7 +201,7 @@ static int maxpool_bwd_t(const dbx_view* x, const dbx_view* dy, const dbx_view* 
     VIEW_VEC_CHECK(T, x, "maxpool_bwd x"); VIEW_VEC_CHECK(T, dy, "maxpool_bwd dy"); VIEW_VEC_CHECK(T, dx, "maxpool_bwd dx");
     DBX_REQUIRE(dy->h == x->h / 2 && dy->w == x->w / 2 && dx->h == x->h && dx->w == x->w && dx->c == x->c && dy->c == x->c,
                 "maxpool_bwd: shape mismatch");
-    const int64_t total = (int64_t)x->n * x->h * x->w * (x->c / Vec<T>::N);
+    const int64_t total = (int64_t)x->n * ((x->h + 1) / 2) * ((x->w + 1) / 2) * (x->c / Vec<T>::N);
     hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, make_geo<T>(x), make_geo<T>(dy),
                        make_geo<T>(dx), dy->h, dy->w, accumulate, relu_gate);
     DBX_LAUNCH_CHECK();

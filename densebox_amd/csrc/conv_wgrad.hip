@@ -356,28 +356,42 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
     }
 }
 
-// dw[co][ci][tap] = sum_s partial[s][co][tap][ci]   (fixed summation order), db[co] = sum_s bpartial[s][co]
+// dw[co][ci][tap] = sum_s partial[s][co][tap][ci], db[co] = sum_s bpartial[s][co].  Deterministic: 4 lanes own one output
+// element, lane g sums splits g, g+4, ... in ascending order, and the four partial sums are combined in the fixed order
+// ((s0+s1)+(s2+s3)).  Consecutive elements of a slab row map to consecutive 4-lane groups (coalesced 16-element reads).
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits, int co,
                                     int ci, int taps, int co_pad, int ci_pad, float* __restrict__ dw, float* __restrict__ db,
                                     int accumulate) {
     const long long total = (long long)co * taps * ci;
     const long long slab = (long long)co_pad * taps * ci_pad;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total + co; i += (long long)gridDim.x * blockDim.x) {
+    const int g = threadIdx.x >> 6;                                   // split group 0..3 (one wave each)
+    const int e = threadIdx.x & 63;
+    __shared__ float red[4][64];
+    for (long long base = (long long)blockIdx.x * 64; base < total + co; base += (long long)gridDim.x * 64) {
+        const long long i = base + e;
+        float s = 0.f;
+        long long dst = -1;
+        bool is_b = false;
         if (i < total) {
             const int c = (int)(i % ci);
             const int t = (int)((i / ci) % taps);
             const int o = (int)(i / ((long long)ci * taps));
             const long long src = ((long long)o * taps + t) * ci_pad + c;
-            float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += partial[k * slab + src];
-            const long long dst = ((long long)o * ci + c) * taps + t;
-            dw[dst] = accumulate ? dw[dst] + s : s;
-        } else if (db) {
+            for (int k = g; k < splits; k += 4) s += partial[k * slab + src];
+            dst = ((long long)o * ci + c) * taps + t;
+        } else if (i < total + co && db) {
             const int o = (int)(i - total);
-            float s = 0.f;
-            for (int k = 0; k < splits; ++k) s += bpartial[(long long)k * co_pad + o];
-            db[o] = accumulate ? db[o] + s : s;
+            for (int k = g; k < splits; k += 4) s += bpartial[(long long)k * co_pad + o];
+            dst = o; is_b = true;
         }
+        red[g][e] = s;
+        __syncthreads();
+        if (g == 0 && dst >= 0) {
+            const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            float* out = is_b ? db : dw;
+            out[dst] = accumulate ? out[dst] + v : v;
+        }
+        __syncthreads();
     }
 }
 
@@ -452,7 +466,7 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     }
     DBX_LAUNCH_CHECK();
     const long long total = (long long)co * p.taps * ci + co;
-    int blocks = (int)((total + 255) / 256); blocks = blocks > 4096 ? 4096 : blocks;
+    int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, co, ci, p.taps, p.co_pad,
                        p.ci_pad, dw, db, accumulate);
     DBX_LAUNCH_CHECK();

@@ -147,7 +147,8 @@ class Engine:
         ent = self.wcache.get(key)
         if ent is not None and ent[0] == versions:
             return ent[1]
-        t = builder()
+        # re-pack into the existing buffer when there is one: its zero padding never changes
+        t = builder(ent[1] if ent is not None else None)
         self.wcache[key] = (versions, t)
         return t
 
@@ -169,7 +170,7 @@ class Engine:
         ent = self.bias_cache.get(key)
         if ent is not None and ent[0] == ver:
             return ent[1]
-        b = torch.zeros(pad_to, dtype=torch.float32, device=ps[0].device)
+        b = ent[1] if ent is not None else torch.zeros(pad_to, dtype=torch.float32, device=ps[0].device)
         o = 0
         for p in ps:
             b[o:o + p.numel()].copy_(p.detach())
@@ -179,15 +180,15 @@ class Engine:
 
     def _w_fwd(self, dt, stem, cin_pad, cout_pad):
         w = self._param(stem + '.weight')
-        return self._packed((stem, 0, dt), lambda: self._pack(dt, 0, w, cout_pad, cin_pad, w.shape[2], w.shape[3]),
+        return self._packed((stem, 0, dt),
+                            lambda old: self._pack(dt, 0, w, cout_pad, cin_pad, w.shape[2], w.shape[3], out=old),
                             (w._version, w.data_ptr()))
 
     def _w_heads1(self, dt):
         heads = _HEADS[self.kind]
         ws = [self._param('conv5_1_%s.weight' % s) for s, _ in heads]
 
-        def build():
-            out = None
+        def build(out):
             for i, w in enumerate(ws):
                 out = self._pack(dt, 0, w, 512 * len(ws), 768, 1, 1, out=out, row_off=512 * i)
             return out
@@ -356,15 +357,15 @@ class Engine:
     def _w_bwd(self, dt, stem, rows_pad, cin_pad):
         """dgrad weights: rows = input channels, K = [flipped tap][output channel]."""
         w = self._param(stem + '.weight')
-        return self._packed((stem, 1, dt), lambda: self._pack(dt, 1, w, rows_pad, cin_pad, w.shape[2], w.shape[3]),
+        return self._packed((stem, 1, dt),
+                            lambda old: self._pack(dt, 1, w, rows_pad, cin_pad, w.shape[2], w.shape[3], out=old),
                             (w._version, w.data_ptr()))
 
     def _w_heads1_bwd(self, dt):
         heads = _HEADS[self.kind]
         ws = [self._param('conv5_1_%s.weight' % s) for s, _ in heads]
 
-        def build():
-            out = None
+        def build(out):
             for i, w in enumerate(ws):
                 out = self._pack(dt, 1, w, 768, 512 * len(ws), 1, 1, out=out, k_off=512 * i)
             return out
