@@ -240,117 +240,152 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 // 512 threads = 8 waves as 4(M) x (BN/64)(N)... each wave still owns a 64x64 output tile.  The A (pixel) and B (weight)
 // tiles of one 128-byte K step go global -> LDS directly with global_load_lds_dwordx4 (no VGPR staging, no ds_write
 // pass) into a 3-stage ring; loads run two K steps ahead of the MFMAs and are retired with a COUNTED vmcnt, one raw
-// s_barrier per step:
+// s_barrier per step.  Workgroups are PERSISTENT (one per CU) and the load stream runs across tile boundaries, so the
+// ring never drains: while a tile's epilogue stores, the first two K steps of the next tile are already in flight:
 //      wait(my loads of step ks) ; barrier ; issue loads of step ks+2 into the stage read at ks-1 ; MFMAs of step ks
 // The LDS image of a wave-instruction is lane-linear (8 rows x 128 B), so the XOR swizzle that keeps ds_read_b128
 // conflict-free is applied to the per-lane SOURCE address (logical chunk = physical chunk ^ ((row>>1)&7)).
-template <typename T, int BM, int BN>
+// Template: BM x BN tile, BKB bytes of K per row per step (128 or 64), STAGES-deep ring, WM x WN waves (8 total).
+//   <256,128,128,3,4,2> / <256,64,128,3,8,1>: 64x64 (32x64) per wave, loads 2 steps ahead
+//   <256,256, 64,4,2,4>                     : 128x64 per wave, loads 3 steps ahead; 1.5x fewer staged bytes per FLOP
+template <int BKB> __device__ __forceinline__ int dma_swz(int row) {        // XOR mask (in 16-byte chunks) of a tile row
+    if (BKB == 128) return (row >> 1) & 7;                                   // 2 rows per 256-B bank row
+    else return (0x1320 >> (((row >> 2) & 3) * 4)) & 3;                      // 4 rows per bank row: F = {0,2,3,1}
+}
+
+template <typename T, int BM, int BN, int BKB, int STAGES, int WM, int WN>
 __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
-    constexpr int WN = BN / 64, WM = 8 / WN;               // 8 waves
-    constexpr int WTM = BM / WM, WTN = 64;                 // 64x64 per wave (32x64 for the 64-cout tile)
-    constexpr int MI = WTM / 16, NI = 4;
+    static_assert(WM * WN == 8, "8 waves");
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
     constexpr int ES = sizeof(T);
-    constexpr int STAGE = (BM + BN) * 128;
-    constexpr int A_PER_WAVE = BM / 8 / 8;                 // 1-KiB pieces (8 rows) of the A tile per wave per step
-    constexpr int B_PER_WAVE = BN / 8 / 8;
+    constexpr int STAGE = (BM + BN) * BKB;
+    constexpr int CPRW = BKB / 16;                         // 16-byte chunks per tile row
+    constexpr int RPP = 64 / CPRW;                         // tile rows per 1-KiB piece (one wave-instruction)
+    constexpr int A_PER_WAVE = BM / RPP / 8;
+    constexpr int B_PER_WAVE = BN / RPP / 8;
     constexpr int LOADS = A_PER_WAVE + B_PER_WAVE;
+    constexpr int DEPTH = STAGES - 1;                      // K steps in flight ahead of the MFMAs
+    constexpr int KK = BKB / 64;                           // MFMA K-slices (64 bytes) per step
+    static_assert(A_PER_WAVE >= 1 && B_PER_WAVE >= 1, "tile too small for 8 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-
-    int bid = blockIdx.x;
-    {
-        const int q = a.nblocks >> 3, r = a.nblocks & 7, xcd = bid & 7, j = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-    }
-    const int tile_m = bid / a.ntile_n, tile_n = bid - tile_m * a.ntile_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-    // ---- per-lane source pointers: piece p of this wave covers tile rows 8*(wave*PER_WAVE + p) + (lane>>3)
-    const int lr = lane >> 3, lc = lane & 7;
-    const char* arow[A_PER_WAVE];
-#pragma unroll
-    for (int p = 0; p < A_PER_WAVE; ++p) {
-        const int row = 8 * (wave * A_PER_WAVE + p) + lr;
-        int m = m0 + row;
-        m = m < a.M ? m : a.M - 1;
-        const int n = m / a.HoWo, r = m - n * a.HoWo;
-        const int oy = r / a.Wo, ox = r - oy * a.Wo;
-        const int chunk = lc ^ ((row >> 1) & 7);
-        arow[p] = a.x + ((size_t)(n * a.x_hp + oy + a.x_org) * a.x_wp + (ox + a.x_org)) * (size_t)a.x_ld * ES + chunk * 16;
-    }
-    const char* brow[B_PER_WAVE];
-#pragma unroll
-    for (int p = 0; p < B_PER_WAVE; ++p) {
-        const int row = 8 * (wave * B_PER_WAVE + p) + lr;
-        const int chunk = lc ^ ((row >> 1) & 7);
-        brow[p] = a.w + (size_t)(n0 + row) * a.ktot_bytes + chunk * 16;
-    }
+    const int lr = lane / CPRW, lc = lane % CPRW;
     const int pix_bytes = a.x_ld * ES;
+    const int nk = a.ksteps * (128 / BKB);                 // a.ksteps counts 128-byte steps
 
-    // issue-side K bookkeeping (uniform): byte offset of the current tap and position inside its channel run
-    int is_within = 0, is_kx = 0, is_tapoff = 0, is_k = 0;
-    auto issue = [&](int stage) {
+    // ---- persistent tile schedule.  Workgroup b runs on XCD b%8: give every XCD one contiguous range of tiles and let
+    // its workgroups walk that range with stride (workgroups per XCD), so concurrently running tiles are neighbours
+    // (the N-tiles of one pixel tile share the A panel, adjacent pixel tiles share halo rows) in ONE L2.
+    const int NT = a.nblocks, G = gridDim.x;
+    int t_cur, t_end, t_stride;
+    if ((G & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, q = NT >> 3, r = NT & 7;
+        const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        t_cur = start + j; t_end = start + q + (xcd < r ? 1 : 0); t_stride = G >> 3;
+    } else { t_cur = blockIdx.x; t_end = NT; t_stride = G; }
+    const int my_tiles = t_cur < t_end ? (t_end - t_cur + t_stride - 1) / t_stride : 0;
+    const int total_steps = my_tiles * nk;
+
+    // ---- issue side: per-lane source pointers of the tile being fetched.  Piece p of this wave covers tile rows
+    // RPP*(wave*PER_WAVE + p) + lr; the LDS image of a piece is lane-linear, so the swizzle goes on the source.
+    const char* arow[A_PER_WAVE];
+    const char* brow[B_PER_WAVE];
+    int is_tile = t_cur, is_within = 0, is_kx = 0, is_tapoff = 0, is_k = 0, is_stage = 0;
+    auto set_tile = [&](int tile) {
+        const int tile_m = tile / a.ntile_n, tile_n = tile - tile_m * a.ntile_n;
+#pragma unroll
+        for (int p = 0; p < A_PER_WAVE; ++p) {
+            const int row = RPP * (wave * A_PER_WAVE + p) + lr;
+            int m = tile_m * BM + row;
+            m = m < a.M ? m : a.M - 1;
+            const int n = m / a.HoWo, r = m - n * a.HoWo;
+            const int oy = r / a.Wo, ox = r - oy * a.Wo;
+            const int chunk = lc ^ dma_swz<BKB>(row);
+            arow[p] = a.x + ((size_t)(n * a.x_hp + oy + a.x_org) * a.x_wp + (ox + a.x_org)) * (size_t)a.x_ld * ES + chunk * 16;
+        }
+#pragma unroll
+        for (int p = 0; p < B_PER_WAVE; ++p) {
+            const int row = RPP * (wave * B_PER_WAVE + p) + lr;
+            const int chunk = lc ^ dma_swz<BKB>(row);
+            brow[p] = a.w + (size_t)(tile_n * BN + row) * a.ktot_bytes + chunk * 16;
+        }
+    };
+    auto issue = [&]() {
         const int aoff = is_tapoff + is_within * 16;
-        char* sbase = smem + stage * STAGE;
+        char* sbase = smem + is_stage * STAGE;
 #pragma unroll
         for (int p = 0; p < A_PER_WAVE; ++p)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(arow[p] + aoff),
                                              (__attribute__((address_space(3))) void*)(sbase + (wave * A_PER_WAVE + p) * 1024), 16, 0, 0);
 #pragma unroll
         for (int p = 0; p < B_PER_WAVE; ++p)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow[p] + is_k * 128),
-                                             (__attribute__((address_space(3))) void*)(sbase + BM * 128 + (wave * B_PER_WAVE + p) * 1024), 16, 0, 0);
-        ++is_k;
-        is_within += 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(brow[p] + is_k * BKB),
+                                             (__attribute__((address_space(3))) void*)(sbase + BM * BKB + (wave * B_PER_WAVE + p) * 1024), 16, 0, 0);
+        is_stage = is_stage == STAGES - 1 ? 0 : is_stage + 1;
+        is_within += CPRW;
         if (is_within == a.cpt) {                           // next tap
             is_within = 0;
             if (++is_kx == a.kw) { is_kx = 0; is_tapoff += (a.x_wp - a.kw + 1) * pix_bytes; }
             else is_tapoff += pix_bytes;
         }
+        if (++is_k == nk) {                                 // roll over to this workgroup's next tile (prefetch across tiles)
+            is_k = 0; is_within = 0; is_kx = 0; is_tapoff = 0;
+            is_tile += t_stride;
+            if (is_tile < t_end) set_tile(is_tile);
+        }
     };
 
-    f32x4 acc[NI][MI];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+    // fragment reads: row (l&15) of a 16-row fragment, logical chunk kk*4 + (l>>4)
     const int fr = lane & 15;
-    const int c0sw = ((lane >> 4) ^ ((lane >> 1) & 7)) << 4;
-    const int rd_a = (wm * WTM + fr) * 128;
-    const int rd_b = BM * 128 + (wn * WTN + fr) * 128;
+    const int c0sw = ((lane >> 4) ^ dma_swz<BKB>(fr)) << 4;   // fragment bases are multiples of 16 rows: mask depends on fr only
+    const int rd_a = (wm * WTM + fr) * BKB;
+    const int rd_b = BM * BKB + (wn * WTN + fr) * BKB;
 
-    const int nk = a.ksteps;
-    issue(0);
-    if (nk > 1) issue(1);
-    int stage = 0;
-    for (int ks = 0; ks < nk; ++ks) {
-        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (ks + 2 < nk) issue(stage >= 1 ? stage - 1 : 2);  // (ks+2)%3 == (ks-1)%3: the stage everyone just finished reading
-        const char* Ab = smem + stage * STAGE + rd_a;
-        const char* Bb = smem + stage * STAGE + rd_b;
+    if (my_tiles == 0) return;
+    set_tile(t_cur);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int co = c0sw ^ (kk << 6);
-            u32x4 wf[NI], xf[MI];
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < total_steps) issue();
+    int stage = 0, gstep = 0;
+    for (int tile = t_cur; tile < t_end; tile += t_stride) {
+        f32x4 acc[NI][MI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const u32x4*)(Bb + ni * 16 * 128 + co);
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const u32x4*)(Ab + mi * 16 * 128 + co);
+            for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nk; ++ks, ++gstep) {
+            // my loads of this step have landed once only the (up to DEPTH-1) younger steps are still outstanding
+            const int younger = total_steps - 1 - gstep;
+            if (younger >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * LOADS) : "memory");
+            else if (DEPTH > 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // everyone's loads landed; everyone left the stage refilled next
+            if (gstep + DEPTH < total_steps) issue();
+            const char* Ab = smem + stage * STAGE + rd_a;
+            const char* Bb = smem + stage * STAGE + rd_b;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
+            for (int kk = 0; kk < KK; ++kk) {
+                const int co = c0sw ^ (kk << 6);
+                u32x4 wf[NI], xf[MI];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) Mma<T>::run(wf[ni], xf[mi], acc[ni][mi]);
+                for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const u32x4*)(Bb + ni * 16 * BKB + co);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const u32x4*)(Ab + mi * 16 * BKB + co);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) Mma<T>::run(wf[ni], xf[mi], acc[ni][mi]);
+            }
+            stage = stage == STAGES - 1 ? 0 : stage + 1;
         }
-        stage = stage == 2 ? 0 : stage + 1;
+        const int tile_m = tile / a.ntile_n, tile_n = tile - tile_m * a.ntile_n;
+        conv_epilogue<T, MI, NI>(a, acc, tile_m * BM, tile_n * BN, wm * WTM, wn * WTN, lane);
     }
-    conv_epilogue<T, MI, NI>(a, acc, m0, n0, wm * WTM, wn * WTN, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -378,15 +413,23 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     return DBX_OK;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int BKB, int STAGES, int WM, int WN>
 static int launch_conv_dma(const ConvArgs& a, hipStream_t s) {
-    constexpr int smem = 3 * (BM + BN) * 128;
+    constexpr int smem = STAGES * (BM + BN) * BKB;
     static bool attr_set = false;
     if (!attr_set) {
-        DBX_HIP(hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        DBX_HIP(hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, BKB, STAGES, WM, WN>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<T, BM, BN>), dim3(a.nblocks), dim3(512), smem, s, a);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        DBX_HIP(hipGetDevice(&dev));
+        DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int grid = a.nblocks < ncu ? a.nblocks : ncu;            // one persistent workgroup per CU
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<T, BM, BN, BKB, STAGES, WM, WN>), dim3(grid), dim3(512), smem, s, a);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }
@@ -442,11 +485,16 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         if (n64) {
             a.ntile_n = y->c <= 64 ? 1 : d->cout_pad / 64;
             a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
-            return launch_conv_dma<T, 256, 64>(a, s);
+            return launch_conv_dma<T, 256, 64, 128, 3, 8, 1>(a, s);
+        }
+        if (d->cout_pad % 256 == 0 && y->c % 256 == 0 && conv_variant() != 2) {      // wide layers: 256x256 tile
+            a.ntile_n = y->c / 256;
+            a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
+            return launch_conv_dma<T, 256, 256, 64, 4, 2, 4>(a, s);
         }
         a.ntile_n = (y->c + 127) / 128;
         a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
-        return launch_conv_dma<T, 256, 128>(a, s);
+        return launch_conv_dma<T, 256, 128, 128, 3, 4, 2>(a, s);
     }
     // tile choice: couts are tiled by 128 unless the layer has 64 (or the result is tiny, e.g. the 512->k heads)
     const bool narrow = (d->cout_pad % 128 != 0) || y->c <= 64;

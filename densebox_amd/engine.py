@@ -222,7 +222,8 @@ class Engine:
             if small:
                 name = 'conv_igemm_kernel<%s,%s,smallc>' % (tn, '256,64,4,1' if narrow else '128,128,2,2')
             else:
-                name = 'conv_igemm_dma_kernel<%s,%s>' % (tn, '256,64' if narrow else '256,128')
+                wide = (not narrow) and cout_pad % 256 == 0 and y.c % 256 == 0
+                name = 'conv_igemm_dma_kernel<%s,%s>' % (tn, '256,64' if narrow else ('256,256' if wide else '256,128'))
             ci = alg_ci if alg_ci is not None else cin_pad
             prof.append({'kernel': name, 'flops': 2.0 * y.n * y.h * y.w * kh * kw * ci * y.c, 'start': ev0, 'end': ev1})
 
