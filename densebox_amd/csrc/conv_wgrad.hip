@@ -29,7 +29,20 @@ struct WgradArgs {
     int shift0;                         // (pad_x - pad_dz - cpad) applied to both ky and kx
     int tiles_co, tiles_ci;
     int rows_per_split;                 // multiple of 32
+    int nsplit;
 };
+
+// Workgroup -> (tile, split).  All tiles of one split stream the same frame rows of dz / x, so they should share an L2:
+// workgroup L runs on XCD L%8; when the split count is a multiple of 8, XCD x owns splits x, x+8, ... and walks
+// (split, tile) with tile fastest.  Pure speed: any mapping is correct.
+__device__ __forceinline__ void wg_tile_split(int ntile, int nsplit, int& tile, int& split) {
+    const int L = blockIdx.x;
+    if ((nsplit & 7) == 0) {
+        const int xcd = L & 7, idx = L >> 3;
+        tile = idx % ntile;
+        split = (idx / ntile) * 8 + xcd;
+    } else { tile = L % ntile; split = L / ntile; }
+}
 
 template <int W> __device__ __forceinline__ int swz16(int r, int b) {   // 2-byte tiles, W channels per row
     if (W == 128) return r * 256 + (b ^ (((r & 3) << 5) | (((r >> 3) & 1) << 7)));
@@ -52,11 +65,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    int t = blockIdx.x;
+    int t, split;
+    wg_tile_split(a.tiles_co * a.tiles_ci * a.taps, a.nsplit, t, split);
     const int tile_ci = t % a.tiles_ci; t /= a.tiles_ci;
     const int tile_co = t % a.tiles_co; t /= a.tiles_co;
     const int tap = t;
-    const int split = blockIdx.y;
     const int ky = tap / a.kw, kx = tap - ky * a.kw;
     const long long shift = (long long)(ky + a.shift0) * a.wp + (kx + a.shift0);
     const long long q0 = (long long)split * a.rows_per_split;
@@ -207,6 +220,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 }
 
 
+
 // ------------------------------------------------------------------------------------------------ 3x3, all taps per workgroup
 // For layers with few channels (Cout, Cin <= 128 at 240x240 / 120x120) the per-tap tiling above is bound by refilling
 // LDS: every tap re-reads the same dz rows and a shifted copy of the same x rows (32 FLOP per byte filled).  Here one
@@ -228,8 +242,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;                           // wave tile 32(co) x 32(ci)
-    const int tile_ci = blockIdx.x % a.tiles_ci, tile_co = blockIdx.x / a.tiles_ci;
-    const int split = blockIdx.y;
+    int t, split;
+    wg_tile_split(a.tiles_co * a.tiles_ci, a.nsplit, t, split);
+    const int tile_ci = t % a.tiles_ci, tile_co = t / a.tiles_ci;
     const long long q0 = (long long)split * a.rows_per_split;
     long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
     const int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
@@ -419,14 +434,15 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     p.Q = (long long)dz->n * (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad);
     const long long tiles = (long long)p.tiles_co * p.tiles_ci * (p.alltaps ? 1 : p.taps);
     const long long steps = (p.Q + 31) / 32;
-    long long splits = (1024 + tiles - 1) / tiles;            // aim for ~4 workgroups per CU
+    long long splits = (1024 + tiles - 1) / tiles;            // aim for ~4 workgroups per CU (2 resident per CU)
     const long long max_by_steps = steps / 16 > 0 ? steps / 16 : 1;   // at least 16 K-steps (512 rows) per split
     if (splits > max_by_steps) splits = max_by_steps;
     if (splits > 256) splits = 256;
     if (splits < 1) splits = 1;
+    if (splits >= 8) splits = (splits + 7) / 8 * 8;           // XCD-aware workgroup mapping wants a multiple of 8
     long long sps = (steps + splits - 1) / splits;
     p.rows_per_split = (int)(sps * 32);
-    p.splits = (int)((p.Q + p.rows_per_split - 1) / p.rows_per_split);
+    p.splits = (int)splits;                                    // trailing splits may be empty: they write zero slabs
     return p;
 }
 
@@ -455,12 +471,12 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.Q = p.Q; a.dz_ld = dz->ld; a.x_ld = x->ld; a.dz_c = dz->c; a.x_c = x->c;
     a.co_pad = p.co_pad; a.ci_pad = p.ci_pad; a.taps = p.taps; a.kw = kw; a.wp = x->w + 2 * x->pad;
     a.shift0 = x->pad - dz->pad - cpad;
-    a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci; a.rows_per_split = p.rows_per_split;
+    a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci; a.rows_per_split = p.rows_per_split; a.nsplit = p.splits;
     if (p.alltaps) {
         if constexpr (sizeof(T) == 2)
-            hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci, p.splits), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), 0, s, a);
     } else {
-        const dim3 grid(p.tiles_co * p.tiles_ci * p.taps, p.splits);
+        const dim3 grid(p.tiles_co * p.tiles_ci * p.taps * p.splits);
         if (p.bmc == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, dim3(256), 0, s, a);
     }
