@@ -409,3 +409,118 @@ extern "C" int dbx_framed_add_ch(int32_t dtype, const dbx_view* src, int32_t c_s
                                  int32_t c_dst_off, void* stream) {
     DBX_DISPATCH_DTYPE(dtype, framed_add_ch_t, src, c_src_off, n_ch, dst, c_dst_off, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------- heads, 512 -> k backward
+// d_hid[m, 512h + c] = 2*mask[m, 512h + c] * sum_{j<k_h} d_out_h[m, j] * W2_h[j][c]   for all heads h in one pass
+// (the data gradient of Conv1x1(512->k) behind nn.Dropout, DenseBox.py:158-162; k <= 8).  Rank-k and write-bound
+// (1 KiB per pixel per head): a streaming kernel -- one wave per (pixel, head), 16 bytes per lane, the lane's k x 8
+// slice of the fp32 master weights in registers -- so that a pixel's 512*nh channels leave as one contiguous burst.
+struct Head2Args { const float* w2[4]; int k[4]; int nh; int slot; };
+
+template <typename T>
+__global__ __launch_bounds__(512) void head2_dgrad_kernel(FrameGeo dout, Head2Args ha, FrameGeo dhid,
+                                                          const unsigned char* __restrict__ mask, int mask_ld) {
+    constexpr int V = Vec<T>::N;                  // channels per lane
+    constexpr int LPH = 512 / V;                  // lanes per (pixel, head): 64 for 16-bit types, 128 for f32
+    const int lph_all = LPH * ha.nh;              // lanes per pixel
+    const int ppb = blockDim.x / lph_all > 0 ? blockDim.x / lph_all : 1;
+    const int sub = threadIdx.x % lph_all;        // position inside the pixel
+    const int hd = sub / LPH, c0 = (sub % LPH) * V;
+    const bool active = threadIdx.x < ppb * lph_all;
+    const int k = ha.k[hd];
+    float w[8][V];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < V; ++i) w[j][i] = (active && j < k) ? ha.w2[hd][j * 512 + c0 + i] : 0.f;
+    if (!active) return;
+    const int nrows = dhid.n * dhid.h;            // one workgroup per image row: no division in the pixel loop
+    for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
+        const int n = row / dhid.h, py = row - n * dhid.h;
+        for (int px = threadIdx.x / lph_all; px < dhid.w; px += ppb) {
+            const int64_t m = (int64_t)row * dhid.w + px;
+            const T* g = (const T*)dout.base + geo_pix(dout, n, py, px) + hd * ha.slot;
+            float gj[8];
+            if constexpr (sizeof(T) == 2) {       // a slot is >= 8 channels = one 16-byte load (padding channels are 0)
+                float tmp[V];
+                load_vec<T>(g, tmp);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gj[j] = tmp[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gj[j] = j < k ? g[j] : 0.f;
+            }
+            float o[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += gj[j] * w[j][i];
+                o[i] = acc;
+            }
+            if (mask) {
+                const unsigned char* mk = mask + (size_t)m * mask_ld + hd * 512 + c0;
+                unsigned char mb[V];
+                if constexpr (V == 8) *(u32x2*)mb = *(const u32x2*)mk; else *(unsigned int*)mb = *(const unsigned int*)mk;
+#pragma unroll
+                for (int i = 0; i < V; ++i) o[i] = mb[i] ? o[i] * 2.f : 0.f;
+            }
+            store_vec<T>((T*)dhid.base + geo_pix(dhid, n, py, px) + hd * 512 + c0, o);
+        }
+    }
+}
+template <typename T>
+static int head2_dgrad_t(const dbx_view* dout, const float* const* w2, const int32_t* k, int nh, const dbx_view* dhid,
+                         const uint8_t* mask, int mask_ld, hipStream_t s) {
+    VIEW_VEC_CHECK(T, dhid, "head2_dgrad d_hid");
+    DBX_REQUIRE(nh >= 1 && nh <= 4 && dhid->c == 512 * nh && dout->c % nh == 0 && dout->c / nh >= 8, "head2_dgrad: nh in 1..4, d_hid of 512*nh channels, d_out of nh slots >= 8 channels");
+    DBX_REQUIRE(dout->n == dhid->n && dout->h == dhid->h && dout->w == dhid->w, "head2_dgrad: shape mismatch");
+    DBX_REQUIRE(((size_t)dout->ptr % 16) == 0 && (dout->ld * sizeof(T)) % 16 == 0 && (dout->c_off * sizeof(T)) % 16 == 0 &&
+                    ((dout->c / nh) * sizeof(T)) % 16 == 0, "head2_dgrad: d_out alignment");
+    Head2Args ha;
+    ha.nh = nh; ha.slot = dout->c / nh;
+    for (int i = 0; i < 4; ++i) { ha.w2[i] = i < nh ? w2[i] : nullptr; ha.k[i] = i < nh ? k[i] : 0; if (i < nh) DBX_REQUIRE(k[i] >= 1 && k[i] <= 8 && w2[i], "head2_dgrad: k in 1..8"); }
+    const int lph_all = (512 / Vec<T>::N) * nh;
+    const int threads = lph_all <= 256 ? 256 : 512;
+    int blocks = dhid->n * dhid->h; blocks = blocks > 8192 ? 8192 : blocks;
+    hipLaunchKernelGGL(head2_dgrad_kernel<T>, dim3(blocks), dim3(threads), 0, s, make_geo<T>(dout), ha, make_geo<T>(dhid), mask, mask_ld);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_head2_dgrad(int32_t dtype, const dbx_view* d_out, const float* const* w2, const int32_t* k, int32_t nh,
+                               const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, void* stream) {
+    if (!d_out || !w2 || !k || !d_hid) { dbx_set_error("head2_dgrad: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(dtype, head2_dgrad_t, d_out, w2, k, nh, d_hid, dropmask, dropmask_ld, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- multi-tensor weight packing
+// One launch re-packs every parameter after an optimizer step (fp32 OIHW -> compute-dtype GEMM layouts, both the forward
+// and the transposed/flipped dgrad copy) and refreshes the padded fp32 bias vectors.  Same element mapping as
+// dbx_pack_weight (conv_igemm.hip); the table lives in device memory and is built once by the host.
+struct PackJob { const float* src; void* dst; int co, ci, taps, mode; long long ktot; int cin_pad, row_off, k_off; };
+template <typename T>
+__global__ void pack_multi_kernel(const PackJob* __restrict__ jobs) {
+    const PackJob j = jobs[blockIdx.y];
+    const long long total = (long long)j.co * j.ci * j.taps;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const float v = j.src[i];
+        if (j.mode == 2) { ((float*)j.dst)[j.row_off + i] = v; continue; }        // bias: plain copy into the padded vector
+        const int t = (int)(i % j.taps);
+        const int c = (int)((i / j.taps) % j.ci);
+        const int o = (int)(i / ((long long)j.taps * j.ci));
+        T* wp = (T*)j.dst;
+        if (j.mode == 0) wp[(long long)(j.row_off + o) * j.ktot + (long long)t * j.cin_pad + j.k_off + c] = from_f32<T>(v);
+        else wp[(long long)(j.row_off + c) * j.ktot + (long long)(j.taps - 1 - t) * j.cin_pad + j.k_off + o] = from_f32<T>(v);
+    }
+}
+template <typename T> static int pack_multi_t(const void* jobs, int count, long long max_elems, hipStream_t s) {
+    int bx = (int)((max_elems + 255) / 256);
+    bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+    hipLaunchKernelGGL(pack_multi_kernel<T>, dim3(bx, count), dim3(256), 0, s, (const PackJob*)jobs);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, void* stream) {
+    DBX_REQUIRE(jobs && count > 0, "pack_multi: empty job table");
+    DBX_DISPATCH_DTYPE(dtype, pack_multi_t, jobs, count, (long long)max_elems, (hipStream_t)stream);
+}

@@ -123,6 +123,11 @@ class Engine:
         self.last_plan = None
         self.grad_sink = None      # optional dist.GradReducer: flat gradient views + readiness callbacks
         self.profile = None        # list -> every conv / wgrad launch appends {kernel, flops, start, end} (HIP events)
+        self._defer = None         # not None while the multi-tensor pack table is being recorded
+        self._defer_keep = []
+        self._table_keys = set()   # cache keys whose buffers the pack table refreshes
+        self._tables = {}          # (dtype, train) -> (device job table, count, max_elems)
+        self._wsig = None
 
     def grad_order(self):
         """Parameter names in the order backward_raw() finishes their gradients (deepest first)."""
@@ -145,8 +150,8 @@ class Engine:
 
     def _packed(self, key, builder, versions):
         ent = self.wcache.get(key)
-        if ent is not None and ent[0] == versions:
-            return ent[1]
+        if ent is not None and (ent[0] == versions or key in self._table_keys):
+            return ent[1]       # table-covered buffers were refreshed by _prepare_weights() at the top of forward
         # re-pack into the existing buffer when there is one: its zero padding never changes
         t = builder(ent[1] if ent is not None else None)
         self.wcache[key] = (versions, t)
@@ -159,6 +164,12 @@ class Engine:
         if out is None:
             out = torch.zeros(elems * _lib.ESIZE[dt], dtype=torch.uint8, device=w.device)
         co, ci = w.shape[0], w.shape[1]
+        if self._defer is not None:       # table build: record the job, the multi-tensor launch does the work
+            es = _lib.ESIZE[dt]
+            ktot = (kh * kw * cin_pad * es + 127) // 128 * 128 // es
+            self._defer.append((w.data_ptr(), out.data_ptr(), co, ci, kh * kw, mode, ktot, cin_pad, row_off, k_off))
+            self._defer_keep.append(out)
+            return out
         check(self.L.dbx_pack_weight(dt, mode, ptr(w.detach()), co, ci, kh, kw, ptr(out), rows_pad, cin_pad,
                                      row_off, k_off, stream_ptr()))
         return out
@@ -168,13 +179,18 @@ class Engine:
         key = tuple(names)
         ver = tuple((p._version, p.data_ptr()) for p in ps)
         ent = self.bias_cache.get(key)
-        if ent is not None and ent[0] == ver:
+        if ent is not None and (ent[0] == ver or key in self._table_keys):
             return ent[1]
         b = ent[1] if ent is not None else torch.zeros(pad_to, dtype=torch.float32, device=ps[0].device)
         o = 0
         for p in ps:
-            b[o:o + p.numel()].copy_(p.detach())
+            if self._defer is not None:
+                self._defer.append((p.data_ptr(), b.data_ptr(), p.numel(), 1, 1, 2, 0, 0, o, 0))
+            else:
+                b[o:o + p.numel()].copy_(p.detach())
             o += p.numel()
+        if self._defer is not None:
+            self._defer_keep.append(b)
         self.bias_cache[key] = (ver, b)
         return b
 
@@ -193,6 +209,58 @@ class Engine:
                 out = self._pack(dt, 0, w, 512 * len(ws), 768, 1, 1, out=out, row_off=512 * i)
             return out
         return self._packed(('heads1', 0, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+
+    def _weight_getters(self, dt, train, P):
+        """Touch every packed weight / bias the step uses (same calls as forward_raw / backward_raw make)."""
+        kind = self.kind
+        heads = _HEADS[kind]
+        nh = len(heads)
+        for stem, cin, cout in _BACKBONE:
+            self._w_fwd(dt, stem, P.cin0 if cin == 3 else cin, max(64, cout))
+            self._bias([stem], max(64, cout))
+        self._w_heads1(dt)
+        self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
+        for s_, _ in heads:
+            self._w_fwd(dt, 'conv5_2_' + s_, 512, 64)
+            self._bias(['conv5_2_' + s_], 64)
+        if kind != 'DenseBox':
+            self._w_fwd(dt, 'conv6_1_det', P.crf, 64); self._bias(['conv6_1_det'], 64)
+            self._w_fwd(dt, 'conv6_2_det', 64, 64); self._bias(['conv6_2_det'], 64)
+            self._w_fwd(dt, 'conv6_3_det', 64, 64); self._bias(['conv6_3_det'], 64)
+        if train:
+            for stem, cin, cout in _BACKBONE[1:]:
+                self._w_bwd(dt, stem, max(64, cin), cout)
+            self._w_heads1_bwd(dt)
+            if kind != 'DenseBox':
+                self._w_bwd(dt, 'conv6_3_det', 64, P.crf)
+                self._w_bwd(dt, 'conv6_2_det', 64, 64)
+                self._w_bwd(dt, 'conv6_1_det', 64, 64)
+
+    def _prepare_weights(self, dt, train, P):
+        """Re-pack all parameters with ONE kernel launch when any of them changed (e.g. after an optimizer step)."""
+        params = [p for _, p in self.net.named_parameters()]
+        sig = (dt, train, tuple((p._version, p.data_ptr()) for p in params))
+        if sig == self._wsig:
+            return
+        tkey = (dt, train, P.cin0, P.crf, sig[2][0][1])
+        tab = self._tables.get(tkey)
+        if tab is None:
+            import numpy as np
+            self._defer, keys_before = [], set(self.wcache) | set(self.bias_cache)
+            self.wcache.clear(); self.bias_cache.clear(); self._table_keys = set()
+            self._weight_getters(dt, train, P)
+            jobs, self._defer = self._defer, None
+            self._table_keys = set(self.wcache) | set(self.bias_cache)
+            rec = np.zeros(len(jobs), dtype=[('src', '<u8'), ('dst', '<u8'), ('co', '<i4'), ('ci', '<i4'), ('taps', '<i4'),
+                                             ('mode', '<i4'), ('ktot', '<i8'), ('cin_pad', '<i4'), ('row_off', '<i4'),
+                                             ('k_off', '<i4'), ('_pad', '<i4')])
+            for i, j in enumerate(jobs):
+                rec[i] = j + (0,)
+            dev = params[0].device
+            tab = (torch.from_numpy(rec.view(np.uint8).copy()).to(dev), len(jobs), max(j[2] * j[3] * j[4] for j in jobs))
+            self._tables = {tkey: tab}
+        check(self.L.dbx_pack_multi(dt, ptr(tab[0]), tab[1], tab[2], stream_ptr()))
+        self._wsig = sig
 
     # ------------------------------------------------------------------ plumbing
     def plan(self, n, h, w, dt, device, train):
@@ -256,6 +324,7 @@ class Engine:
         self.last_plan = P
         B = P.B
         s = stream_ptr()
+        self._prepare_weights(dt, train, P)
         Xf = X.detach().to(torch.float32).contiguous()
         check(L.dbx_nchw_to_framed(dt, ptr(Xf), 3, C.byref(B['x0'].view()), s))
         RELU = _lib.EPI_BIAS | _lib.EPI_RELU
@@ -457,9 +526,10 @@ class Engine:
         # ---- heads: 512 -> k (per head), dropout, then the shared 768 -> 512*nh GEMM
         for i, (stem, k) in enumerate(heads):
             conv_bwd('conv5_2_' + stem, slot[stem], B['hid'].view(512 * i, 512), 1, 1, 0, k, 512)
-            dgrad('conv5_2_' + stem, slot[stem], B['d_hid'].view(512 * i, 512), 1, 1, 0, 512, P.crf,
-                  epi=_lib.EPI_DROPMASK if P.drop_active else 0,
-                  dropmask=(P.mask_ptr + 512 * i) if P.drop_active else None)
+        w2s = [self._param('conv5_2_%s.weight' % st).detach() for st, _ in heads]      # fp32 [k,512,1,1]
+        check(L.dbx_head2_dgrad(dt, C.byref(B['d_out'].view()), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]),
+                                (C.c_int32 * nh)(*[k for _, k in heads]), nh, C.byref(B['d_hid'].view()),
+                                C.c_void_p(P.mask_ptr) if P.drop_active else None, 512 * nh, s))
         w1n = ['conv5_1_%s.weight' % st for st, _ in heads]
         b1n = ['conv5_1_%s.bias' % st for st, _ in heads]
         if sink is not None:           # the heads' conv5_1 gradients are adjacent in the flat buffer (grad_order)

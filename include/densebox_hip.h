@@ -87,6 +87,17 @@ int dbx_conv_forward(const dbx_conv_desc* d, const dbx_view* x, const void* w_pa
 int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw, int32_t co, int32_t ci, int32_t kh, int32_t kw,
                     void* w_packed, int32_t rows_pad, int32_t cin_pad, int32_t row_off, int32_t k_off, void* stream);
 
+/* All parameters in ONE launch (after an optimizer step).  `jobs` is a device array of
+ *   struct { const float* src; void* dst; int32 co, ci, taps, mode; int64 ktot; int32 cin_pad, row_off, k_off; }
+ * mode 0/1 as dbx_pack_weight, mode 2 = fp32 bias copy into dst[row_off ...] (co = length, ci = taps = 1). */
+int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, void* stream);
+
+/* heads: data gradient of the nh (<= 4) Conv1x1(512->k_h) layers behind Dropout in one rank-k streaming pass:
+ * d_hid[m, 512h+c] = (dropmask ? 2*mask[m,512h+c] : 1) * sum_{j<k_h} d_out[m, slot*h + j] * w2[h][j][c]
+ * d_out: nh equal channel slots (>= 8 each); w2[h]: fp32 [k_h][512]; w2 / k are HOST arrays (DenseBox.py:158-162) */
+int dbx_head2_dgrad(int32_t dtype, const dbx_view* d_out, const float* const* w2, const int32_t* k, int32_t nh,
+                    const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, void* stream);
+
 /* ------------------------------------------------------------------ weight gradient
  * dw[co][ci][ky][kx] (+)= sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-cpad,x+kx-cpad,ci]   (fp32 OIHW, DenseBox.py:2186)
  * db[co] = sum dz.   dz and x must live in frames of identical geometry (same n,h,w,pad).
