@@ -93,6 +93,7 @@ def main():
 
     rank, world, local = init_from_env()
     assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node == --gpus'
+    local = local % torch.cuda.device_count()          # (several ranks may share a GPU under DBX_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     kind, n = args.kind, args.batch
@@ -138,16 +139,19 @@ def main():
     loss_val = float(loss.detach())
     assert np.isfinite(loss_val), 'training step produced a non-finite loss'
 
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream: 3 extra, untimed steps.
+    # EVERY rank runs them (they contain collectives); only rank 0 records events.
+    eng = net.engine()
+    if rank == 0:
+        eng.profile = []
+    for _ in range(3):
+        one_step()
+    barrier()
+
     out = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = n * world * args.steps / dt
-        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (untimed extra steps)
-        eng = net.engine()
-        eng.profile = []
-        for _ in range(3):
-            one_step()
-        torch.cuda.synchronize()
         calls = eng.profile
         eng.profile = None
         fam = {}

@@ -1,0 +1,86 @@
+"""GPU data-parallel equivalence: two ranks (gloo transport, both on cuda:0 -- RCCL needs one device per rank, the
+reducer/step logic is backend-agnostic) each train on half of a batch; parameters after the step must equal the
+single-process step on the concatenated batch (sum-loss => all-reduce SUM without division; global
+positive count => identical mining constants)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+KIND, N_PER, WORLD, LR = 'DenseBoxLMLOC', 2, 2, 1e-8
+
+
+def _data():
+    from densebox_amd import synth, labels as LB
+    N = N_PER * WORLD
+    x, bbox, vert, lab = synth.synth_batch(N, seed=31, neg_frac=0.3)
+    lab[0, 0] = 1.0 if float(bbox[0].abs().sum()) > 0 else 0.0
+    P = int(LB.positive_count(bbox, lab).sum())
+    _, half = LB.neg_counts(P, N)
+    rn = synth.synth_rand_neg_indices(N, half, seed=5)
+    lrn = synth.synth_rand_neg_indices(4 * N, 1, seed=6).reshape(4, N, 1)
+    return x, bbox, vert, lab, rn, lrn
+
+
+def _make_net():
+    import densebox_amd as D
+    from densebox_amd import synth
+    net = getattr(D, KIND)(synth.vgg19_standin(seed=0))
+    synth.fill_params_(net, 11)
+    net = net.cuda().train()
+    net.compute_dtype = 'f32'
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return net
+
+
+def _rank_main(rank, world, port, out_path):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from densebox_amd.dist import DataParallel
+        from densebox_amd.optim import SGD
+        x, bbox, vert, lab, rn, lrn = _data()
+        net = _make_net()
+        dp = DataParallel(net, SGD(net.parameters(), lr=LR), bucket_bytes=4 << 20)
+        sl = slice(rank * N_PER, (rank + 1) * N_PER)
+        loss = dp.step(x[sl].cuda(), bbox[sl], vert[sl], lab[sl], rand_neg_indices=rn[sl], lm_rand_neg_indices=lrn[:, sl])
+        tot = loss.detach().double().cpu().clone()
+        dist.all_reduce(tot)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({'loss': float(tot), 'params': {k: p.detach().cpu() for k, p in net.named_parameters()},
+                        'grads': {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}}, out_path)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process(tmp_path):
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / 'dp.pt')
+    mp.spawn(_rank_main, args=(WORLD, port, out), nprocs=WORLD, join=True)
+    got = torch.load(out)
+    # single process, concatenated batch
+    from densebox_amd.optim import SGD
+    x, bbox, vert, lab, rn, lrn = _data()
+    net = _make_net()
+    opt = SGD(net.parameters(), lr=LR)
+    outs = net(x.cuda())
+    loss = net.loss(outs, bbox, vert, lab, rand_neg_indices=rn, lm_rand_neg_indices=lrn)
+    loss.backward()
+    ref_g = {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}
+    opt.step()
+    assert np.isclose(got['loss'], float(loss.detach()), rtol=1e-6)
+    assert set(got['grads']) == set(ref_g)
+    for k, g in ref_g.items():
+        scale = float(g.abs().max()) + 1e-30
+        assert float((got['grads'][k] - g).abs().max()) <= 2e-5 * scale, k      # fp32 summation order only
+    for k, p in net.named_parameters():
+        assert torch.allclose(got['params'][k], p.detach().cpu(), rtol=0, atol=1e-6 * float(p.abs().max()) + 1e-12), k
