@@ -388,6 +388,166 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ v3: 3x3 band kernel
+// 3x3 / pad 1 layers (the whole backbone, forward and dgrad).  The output tile is BM (256 or 512) CONSECUTIVE pixels of the
+// linearised frame (halo pixels included; their results are simply not stored), so the rows a tap needs are the tile's
+// own rows shifted by a constant: for a fixed ky the three kx taps read rows r+0, r+1, r+2 of ONE band of BM+2 frame rows.
+// One K stage therefore stages a single A band (BM+16 rows x 64 B) plus the weight tiles of the three kx taps and feeds
+// 3 x 32 MFMAs per wave per barrier: 32-53 % fewer bytes through the L2 -> LDS path per FLOP than one-tap-per-stage
+// (the measured limiter of v2), and a third of the barriers.  Pieces (1 KiB = 16 rows x 64 B) are dealt round-robin to
+// the 8 waves; the source-side XOR swizzle and the counted-vmcnt ring are as in v2.
+template <typename T, int BM, int BN, int STAGES, int WM, int WN>
+__global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
+    constexpr int BKB = 64, AR = BM + 16;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int MI = WTM / 16, NI = WTN / 16;
+    constexpr int ES = sizeof(T);
+    constexpr int AP = AR / 16, BP = 3 * BN / 16, TOT = AP + BP;      // 1-KiB pieces per stage
+    constexpr int NP = (TOT + 7) / 8;                                   // per-wave slots
+    constexpr int L_LO = TOT / 8, REM = TOT % 8;
+    constexpr int STAGE = TOT * 1024;
+    constexpr int DEPTH = STAGES - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const bool extra = wave < REM;                                       // this wave owns L_LO + 1 pieces
+
+    int bid = blockIdx.x;
+    {
+        const int q = a.nblocks >> 3, r = a.nblocks & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int tile_m = bid / a.ntile_n, tile_n = bid - tile_m * a.ntile_n;
+    const long long q0 = (long long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int pix_bytes = a.x_ld * ES;
+    const int cin_bytes = a.cpt * 16;
+    const int kc_steps = cin_bytes / BKB;
+    const int nk = 3 * kc_steps;
+
+    // ---- per-lane piece sources.  Slot i of this wave is piece pid = wave + 8 i: an A-band piece (rows 16 pid ..) when
+    // pid < AP, else weight piece pid-AP = (kx tap, 16 cout rows).
+    const int lr = lane >> 2, lc = lane & 3;
+    const char* src[NP];
+    bool is_a[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int pid = wave + 8 * i;
+        is_a[i] = pid < AP;
+        if (pid < AP) {
+            const int row = 16 * pid + lr;
+            const int chunk = lc ^ dma_swz<BKB>(row);
+            // band ky=0 starts one frame row up and one pixel left of the tile (x frame == output frame: x.pad == cpad == 1)
+            src[i] = a.x + ((q0 + row) - a.x_wp - 1) * (long long)pix_bytes + chunk * 16;
+        } else {
+            const int pb = pid - AP;
+            const int kx = pb / (BN / 16), row = 16 * (pb % (BN / 16)) + lr;
+            const int chunk = lc ^ dma_swz<BKB>(row);
+            src[i] = a.w + (size_t)(n0 + row) * a.ktot_bytes + kx * cin_bytes + chunk * 16;
+        }
+    }
+    int is_ky = 0, is_kc = 0, is_stage = 0;
+    auto issue = [&]() {
+        const int aoff = is_ky * a.x_wp * pix_bytes + is_kc * BKB;      // uniform
+        const int boff = is_ky * 3 * cin_bytes + is_kc * BKB;
+        char* sbase = smem + is_stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (i < L_LO || extra)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (is_a[i] ? aoff : boff)),
+                                                 (__attribute__((address_space(3))) void*)(sbase + (wave + 8 * i) * 1024), 16, 0, 0);
+        }
+        is_stage = is_stage == STAGES - 1 ? 0 : is_stage + 1;
+        if (++is_kc == kc_steps) { is_kc = 0; ++is_ky; }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets.  A: row fr + kx of a 16-row block (block bases are multiples of 16, so the swizzle depends on
+    // fr + kx only); B: row fr.
+    const int fr = lane & 15, g = lane >> 4;
+    int offA[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) offA[kx] = (wm * WTM + fr + kx) * BKB + ((g ^ dma_swz<BKB>(fr + kx)) << 4);
+    const int offB = AP * 1024 + (wn * WTN + fr) * BKB + ((g ^ dma_swz<BKB>(fr)) << 4);
+
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < nk) issue();
+    int stage = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int younger = nk - 1 - ks;
+        // counted wait: my loads of this stage are done once only `min(younger, DEPTH-1)` stages of mine are outstanding
+        if (extra) {
+            if (younger >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * (L_LO + 1)) : "memory");
+            else if (DEPTH > 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L_LO + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (younger >= DEPTH - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((DEPTH - 1) * L_LO) : "memory");
+            else if (DEPTH > 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L_LO) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (ks + DEPTH < nk) issue();
+        const char* Sb = smem + stage * STAGE;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            u32x4 wf[NI], xf[MI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const u32x4*)(Sb + offB + kx * BN * BKB + ni * 16 * BKB);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const u32x4*)(Sb + offA[kx] + mi * 16 * BKB);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) Mma<T>::run(wf[ni], xf[mi], acc[ni][mi]);
+        }
+        stage = stage == STAGES - 1 ? 0 : stage + 1;
+    }
+
+    // ---- epilogue over frame pixels: only interior pixels are stored (the frame of y stays zero)
+    const int cb = n0 + wn * WTN + (lane >> 4) * 4;
+    const int epi = a.epi;
+    const int fpix = a.x_hp * a.x_wp;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long long q = q0 + wm * WTM + mi * 16 + (lane & 15);
+        const int n = (int)(q / fpix), rem = (int)(q - (long long)n * fpix);
+        const int fy = rem / a.x_wp, fx = rem - fy * a.x_wp;
+        if (n >= a.M / a.HoWo || fy < 1 || fy > a.x_hp - 2 || fx < 1 || fx > a.x_wp - 2) continue;
+        const int oy = fy - 1, ox = fx - 1;
+        const size_t ypix = ((size_t)(n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
+        const size_t gpix = ((size_t)(n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int c = cb + ni * 16;
+            if (c >= a.cout_valid) continue;
+            f32x4 v = acc[ni][mi];
+            if (epi & DBX_EPI_BIAS) v += *(const f32x4*)(a.bias + c);
+            if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (epi & DBX_EPI_GATE) {
+                const T* gt = (const T*)a.gate + gpix + c;
+                v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
+                v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
+            }
+            T* o = (T*)a.y + ypix + c;
+            if (epi & DBX_EPI_ACCUM) { v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]); }
+            if constexpr (sizeof(T) == 2) {
+                T pk[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+                *(u32x2*)o = *(const u32x2*)pk;
+            } else {
+                *(f32x4*)o = v;
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static int64_t packed_k_elems(const dbx_conv_desc* d) {
     const int es = dbx_esize(d->dtype);
@@ -430,6 +590,21 @@ static int launch_conv_dma(const ConvArgs& a, hipStream_t s) {
     }
     const int grid = a.nblocks < ncu ? a.nblocks : ncu;            // one persistent workgroup per CU
     hipLaunchKernelGGL((conv_igemm_dma_kernel<T, BM, BN, BKB, STAGES, WM, WN>), dim3(grid), dim3(512), smem, s, a);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+template <typename T, int BM, int BN, int STAGES, int WM, int WN>
+static int launch_conv_band(const ConvArgs& a, hipStream_t s) {
+    constexpr int smem = STAGES * ((BM + 16) / 16 + 3 * BN / 16) * 1024;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_band_kernel<T, BM, BN, STAGES, WM, WN>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_band_kernel<T, BM, BN, STAGES, WM, WN>), dim3(a.nblocks), dim3(512), smem, s, a);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }
@@ -479,6 +654,27 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.epi = d->epilogue; a.dm_ld = dm_ld;
     DBX_REQUIRE(a.M > 0 && (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < (int64_t)1 << 40, "conv: empty or oversized input");
 
+    // 3x3 / pad 1 on congruent frames (x.pad == 1), 16-bit, plain NHWC epilogue: the band kernel over the linearised frame
+    if (!smallc && sizeof(T) == 2 && conv_variant() == 0 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 &&
+        !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK)) && (d->cin_pad * ES) % 64 == 0 && y->c % 64 == 0) {
+        const long long Q = (long long)x->n * a.x_hp * a.x_wp;
+        const int tiles256 = (int)((Q + 255) / 256), tiles512 = (int)((Q + 511) / 512);
+        const bool tall = conv_variant() != 4 && tiles512 >= 1024;      // enough work for >= 4 tall tiles per CU
+        if (y->c % 256 == 0 && d->cout_pad % 256 == 0) {
+            a.ntile_n = y->c / 256; a.nblocks = tiles256 * a.ntile_n;
+            return launch_conv_band<T, 256, 256, 2, 2, 4>(a, s);
+        }
+        if (y->c % 128 == 0 && d->cout_pad % 128 == 0) {
+            a.ntile_n = y->c / 128;
+            if (tall) { a.nblocks = tiles512 * a.ntile_n; return launch_conv_band<T, 512, 128, 2, 4, 2>(a, s); }
+            a.nblocks = tiles256 * a.ntile_n;
+            return launch_conv_band<T, 256, 128, 3, 4, 2>(a, s);
+        }
+        a.ntile_n = y->c / 64;
+        if (tall) { a.nblocks = tiles512 * a.ntile_n; return launch_conv_band<T, 512, 64, 3, 8, 1>(a, s); }
+        a.nblocks = tiles256 * a.ntile_n;
+        return launch_conv_band<T, 256, 64, 4, 8, 1>(a, s);
+    }
     // LDS-DMA ring kernel: any non-small-Cin layer (f16/bf16/f32 alike); 256x128 tiles, 256x64 when the layer has 64 couts
     if (!smallc && conv_variant() != 1 && a.ksteps >= 2) {
         const bool n64 = (d->cout_pad % 128 != 0) || y->c <= 64;

@@ -37,9 +37,9 @@ class Buf:
         self.es = _lib.ESIZE[dtype_id]
         self.hp, self.wp = h + 2 * pad, w + 2 * pad
         self.bytes = n * self.hp * self.wp * c * self.es
-        # guard band: the weight-gradient kernel walks the frame linearly and reads taps up to (wp+1)*kmax pixels
-        # before/after it; keep those reads inside the (zeroed) allocation
-        self.guard = _align((self.wp + 2) * c * self.es * 4)
+        # guard band: the weight-gradient and 3x3 band kernels walk the frame linearly and read up to a tile (512+16
+        # pixels) plus a frame row before/after it; keep those reads inside the (zeroed) allocation
+        self.guard = _align(max(4 * (self.wp + 2), 576 + self.wp) * c * self.es)
         self.base = None     # device address of element (0,-pad,-pad,0)
 
     def view(self, c_off=0, c=None):
@@ -287,8 +287,14 @@ class Engine:
             narrow = (cout_pad % 128 != 0) or y.c <= 64
             small = cin_pad * _lib.ESIZE[dt] < 128
             tn = ('f16', 'bf16', 'f32')[dt]
+            band = (not small) and dt != _lib.F32 and kh == 3 and kw == 3 and cpad == 1 and x.pad == 1 and \
+                not (epi & (_lib.EPI_F32_NCHW | _lib.EPI_DROPMASK)) and y.c % 64 == 0
             if small:
                 name = 'conv_igemm_kernel<%s,%s,smallc>' % (tn, '256,64,4,1' if narrow else '128,128,2,2')
+            elif band:
+                bn = 256 if (y.c % 256 == 0 and cout_pad % 256 == 0) else (128 if (y.c % 128 == 0 and cout_pad % 128 == 0) else 64)
+                tall = bn < 256 and (x.n * (x.h + 2) * (x.w + 2) + 511) // 512 >= 1024
+                name = 'conv3x3_band_kernel<%s,%d,%d>' % (tn, 512 if tall else 256, bn)
             else:
                 wide = (not narrow) and cout_pad % 256 == 0 and y.c % 256 == 0
                 name = 'conv_igemm_dma_kernel<%s,%s>' % (tn, '256,64' if narrow else ('256,256' if wide else '256,128'))

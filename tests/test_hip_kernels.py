@@ -20,7 +20,7 @@ def framed(x_nchw, pad, tdt):
     """NCHW fp32 -> zero-framed NHWC tensor (with zero guard bands) + the View."""
     n, c, h, w = x_nchw.shape
     hp, wp = h + 2 * pad, w + 2 * pad
-    guard = 8 * wp * c
+    guard = max(8 * wp, 576 + wp) * c
     flat = torch.zeros(2 * guard + n * hp * wp * c, dtype=tdt, device='cuda')
     t = flat[guard:guard + n * hp * wp * c].view(n, hp, wp, c)
     t[:, pad:pad + h, pad:pad + w] = x_nchw.permute(0, 2, 3, 1).to(tdt)

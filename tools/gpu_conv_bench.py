@@ -19,7 +19,7 @@ KEEP = []
 def framed(n, h, c, pad=1):
     # zero guard band before/after the frame: the weight-gradient kernel over-reads by a few frame rows
     hp = h + 2 * pad
-    guard = 8 * hp * c
+    guard = max(8 * hp, 576 + hp) * c
     flat = torch.zeros(guard * 2 + n * hp * hp * c, dtype=tdt, device='cuda')
     KEEP.append(flat)
     t = flat[guard:guard + n * hp * hp * c].view(n, hp, hp, c)

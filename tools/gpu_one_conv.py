@@ -11,7 +11,7 @@ N = int(sys.argv[7]) if len(sys.argv) > 7 else 64
 dt = _lib.DTYPE_ID[dtn]; L = _lib.lib()
 tdt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dtn]
 def framed(n, h, c, pad=1):
-    hp = h + 2 * pad; guard = 8 * hp * c
+    hp = h + 2 * pad; guard = max(8 * hp, 576 + hp) * c
     flat = torch.zeros(guard * 2 + n * hp * hp * c, dtype=tdt, device='cuda')
     t = flat[guard:guard + n * hp * hp * c].view(n, hp, hp, c)
     t[:, pad:h + pad, pad:h + pad] = torch.randn((n, h, h, c), device='cuda').to(tdt)

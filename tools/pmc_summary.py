@@ -14,5 +14,5 @@ except Exception as ex:
 by = collections.defaultdict(dict)
 for k, n, v, c in rows: by[re.sub(r'\(.*\)$', '', k)][n] = v
 for k, d in by.items():
-    if 'conv_igemm' in k or 'wgrad' in k:
+    if 'conv' in k or 'wgrad' in k:
         print(k[:100]); [print('    %-32s %16.1f' % (n, v)) for n, v in sorted(d.items())]
