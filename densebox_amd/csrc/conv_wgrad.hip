@@ -52,12 +52,14 @@ template <int W> __device__ __forceinline__ int swz16(int r, int b) {   // 2-byt
 template <typename T, int BMC, int BNC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     constexpr int ES = sizeof(T);
+    // frame rows per K step: 64 for the 16-bit 128x128 tile (32 MFMAs per wave per barrier), else 32
+    constexpr int R = (ES == 2 && BMC == 128) ? 64 : 32;
     constexpr int WTM = BMC / 2, WTN = BNC / 2;             // 2x2 waves over (co, ci)
     constexpr int MI = WTM / 16, NI = WTN / 16;
     constexpr int CPR_A = BMC * ES / 16, CPR_B = BNC * ES / 16;   // 16-byte chunks per tile row
-    constexpr int LD_A = 32 * CPR_A / 256, LD_B = 32 * CPR_B / 256;  // chunks per thread per step
+    constexpr int LD_A = R * CPR_A / 256, LD_B = R * CPR_B / 256;    // chunks per thread per step
     constexpr int RSTEP_A = 256 / CPR_A, RSTEP_B = 256 / CPR_B;
-    constexpr int A_BYTES = 32 * BMC * ES, B_BYTES = 32 * BNC * ES;
+    constexpr int A_BYTES = R * BMC * ES, B_BYTES = R * BNC * ES;
     __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
     char* As = smem;
     char* Bs = smem + 2 * A_BYTES;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const long long shift = (long long)(ky + a.shift0) * a.wp + (kx + a.shift0);
     const long long q0 = (long long)split * a.rows_per_split;
     long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
-    const int nsteps = q1 > q0 ? (int)((q1 - q0 + 31) / 32) : 0;
+    const int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
     const bool do_bias = (tile_ci == 0 && tap == 0 && a.bpartial != nullptr);
 
     // ---- loaders
@@ -88,9 +90,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     auto gload = [&](int s) {
 #pragma unroll
-        for (int i = 0; i < LD_A; ++i) areg[i] = a_ok ? *(const u32x4*)(ap + (s * 32LL + i * RSTEP_A) * a_row) : zero4;
+        for (int i = 0; i < LD_A; ++i) areg[i] = a_ok ? *(const u32x4*)(ap + ((long long)s * R + i * RSTEP_A) * a_row) : zero4;
 #pragma unroll
-        for (int i = 0; i < LD_B; ++i) breg[i] = b_ok ? *(const u32x4*)(bp + (s * 32LL + i * RSTEP_B) * b_row) : zero4;
+        for (int i = 0; i < LD_B; ++i) breg[i] = b_ok ? *(const u32x4*)(bp + ((long long)s * R + i * RSTEP_B) * b_row) : zero4;
     };
     auto lds_off_a = [&](int r, int b) { if constexpr (ES == 2) return swz16<BMC>(r, b); else return r * BMC * 4 + b; };
     auto lds_off_b = [&](int r, int b) { if constexpr (ES == 2) return swz16<BNC>(r, b); else return r * BNC * 4 + b; };
@@ -133,38 +135,42 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             // lane l of 16-lane group g: tr-read of the 4x16 block [q = 8g+4h .. +3][c0 .. c0+15] delivers, to lane i,
             // the 4 consecutive q of channel c0+i: out[i][j] = in[lane 4j + (i>>2)][i&3]
             const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
-            u32x4 af[MI], bf[NI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int cbyte = (wm * WTM + mi * 16) * 2 + csub;
-                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4v*)(Ab + swz16<BMC>(8 * g + rsub, cbyte)));
-                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4v*)(Ab + swz16<BMC>(8 * g + 4 + rsub, cbyte)));
-                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-                af[mi] = (u32x4){l2.x, l2.y, h2.x, h2.y};
-            }
+            for (int hh = 0; hh < R / 32; ++hh) {
+                const int r0 = hh * 32 + 8 * g + rsub;
+                u32x4 af[MI], bf[NI];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int cbyte = (wn * WTN + ni * 16) * 2 + csub;
-                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4v*)(Bb + swz16<BNC>(8 * g + rsub, cbyte)));
-                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) short4v*)(Bb + swz16<BNC>(8 * g + 4 + rsub, cbyte)));
-                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-                bf[ni] = (u32x4){l2.x, l2.y, h2.x, h2.y};
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int cbyte = (wm * WTM + mi * 16) * 2 + csub;
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4v*)(Ab + swz16<BMC>(r0, cbyte)));
+                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4v*)(Ab + swz16<BMC>(r0 + 4, cbyte)));
+                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    af[mi] = (u32x4){l2.x, l2.y, h2.x, h2.y};
+                }
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    if constexpr (sizeof(T) == 2 && DType<T>::id == DBX_F16)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mi]),
-                                                                             __builtin_bit_cast(f16x8, bf[ni]), acc[mi][ni], 0, 0, 0);
-                    else
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]),
-                                                                              __builtin_bit_cast(bf16x8, bf[ni]), acc[mi][ni], 0, 0, 0);
+                    const int cbyte = (wn * WTN + ni * 16) * 2 + csub;
+                    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4v*)(Bb + swz16<BNC>(r0, cbyte)));
+                    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) short4v*)(Bb + swz16<BNC>(r0 + 4, cbyte)));
+                    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+                    bf[ni] = (u32x4){l2.x, l2.y, h2.x, h2.y};
                 }
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        if constexpr (sizeof(T) == 2 && DType<T>::id == DBX_F16)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mi]),
+                                                                                 __builtin_bit_cast(f16x8, bf[ni]), acc[mi][ni], 0, 0, 0);
+                        else
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]),
+                                                                                  __builtin_bit_cast(bf16x8, bf[ni]), acc[mi][ni], 0, 0, 0);
+                    }
+            }
         } else {
             // f32: A[i][k=g] = dz[q=4kk+g][co0+i], B[k=g][j] = x[q=4kk+g][ci0+j]
             const int g = lane >> 4, i16 = lane & 15;
@@ -441,6 +447,7 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     if (splits < 1) splits = 1;
     if (splits >= 8) splits = (splits + 7) / 8 * 8;           // XCD-aware workgroup mapping wants a multiple of 8
     long long sps = (steps + splits - 1) / splits;
+    sps = (sps + 1) / 2 * 2;                                   // whole 64-row K steps for the R=64 kernel
     p.rows_per_split = (int)(sps * 32);
     p.splits = (int)splits;                                    // trailing splits may be empty: they write zero slabs
     return p;
