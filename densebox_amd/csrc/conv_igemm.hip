@@ -496,18 +496,26 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         if (ks + DEPTH < nk) issue();
         const char* Sb = smem + stage * STAGE;
+        // software pipeline over the three taps: the fragments of tap kx+1 are read while tap kx's MFMAs run
+        u32x4 wf[2][NI], xf[2][MI];
+        auto rd = [&](int kx, u32x4 (&w)[NI], u32x4 (&x)[MI]) {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            u32x4 wf[NI], xf[MI];
+            for (int ni = 0; ni < NI; ++ni) w[ni] = *(const u32x4*)(Sb + offB + kx * BN * BKB + ni * 16 * BKB);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) wf[ni] = *(const u32x4*)(Sb + offB + kx * BN * BKB + ni * 16 * BKB);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) xf[mi] = *(const u32x4*)(Sb + offA[kx] + mi * 16 * BKB);
+            for (int mi = 0; mi < MI; ++mi) x[mi] = *(const u32x4*)(Sb + offA[kx] + mi * 16 * BKB);
+        };
+        auto mm = [&](u32x4 (&w)[NI], u32x4 (&x)[MI]) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) Mma<T>::run(wf[ni], xf[mi], acc[ni][mi]);
-        }
+                for (int mi = 0; mi < MI; ++mi) Mma<T>::run(w[ni], x[mi], acc[ni][mi]);
+        };
+        rd(0, wf[0], xf[0]);
+        rd(1, wf[1], xf[1]);
+        mm(wf[0], xf[0]);
+        rd(2, wf[0], xf[0]);
+        mm(wf[1], xf[1]);
+        mm(wf[0], xf[0]);
         stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
 

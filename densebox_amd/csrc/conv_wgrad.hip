@@ -377,6 +377,122 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ 3x3 with Cin <= 8 (conv1_1)
+// dW[co][tap][c] for an 8-channel (one 16-byte chunk per pixel) input: the GEMM's N dimension is (tap, channel) = 72
+// columns -> five 16-column fragments (two taps x 8 channels each) instead of nine taps x a 64-channel tile that is 7/8
+// padding.  Each transpose-read lane chooses its own LDS address, so a fragment gathers its two taps straight from the
+// row bands.  The kernel streams dz once (HBM-bound: 472 MB for conv1_1 at batch 64) with up to 8 workgroups per CU.
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad3x3_c8_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit tiles");
+    constexpr int R = 32, BAND = R + 2, XROWS = 3 * BAND + 2;           // +2: a zero row for the unused 10th tap, padding
+    constexpr int A_BYTES = R * 128, X_BYTES = XROWS * 16;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + X_BYTES)];
+    char* As = smem;
+    char* Xs = smem + 2 * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave w owns couts 16w .. 16w+15
+    int tile, split;
+    wg_tile_split(1, a.nsplit, tile, split);
+    const long long q0 = (long long)split * a.rows_per_split;
+    long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
+    const int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
+    const bool do_bias = a.bpartial != nullptr;
+
+    const int ca = tid & 7, ra = tid >> 3;
+    const bool a_ok = ca * 16 < a.dz_c * 2;
+    const char* ap = a.dz + (q0 + ra) * (long long)a.dz_ld * 2 + ca * 16;
+    const long long a_row = (long long)a.dz_ld * 2, b_row = (long long)a.x_ld * 2;
+    const bool x_ld_ok = tid < 3 * BAND;
+    const int xband = tid / BAND, xj = tid - xband * BAND;
+    const char* xp = a.x + (q0 + (long long)(xband + a.shift0) * a.wp + a.shift0 + xj) * b_row;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    if (tid < 2) { *(u32x4*)(Xs + (3 * BAND + tid) * 16) = zero4; *(u32x4*)(Xs + X_BYTES + (3 * BAND + tid) * 16) = zero4; }
+    u32x4 areg, xreg;
+    auto gload = [&](int s) {
+        areg = a_ok ? *(const u32x4*)(ap + (long long)s * R * a_row) : zero4;
+        xreg = x_ld_ok ? *(const u32x4*)(xp + (long long)s * R * b_row) : zero4;
+    };
+    auto lstore = [&](int buf) {
+        *(u32x4*)(As + buf * A_BYTES + swz16<64>(ra, ca * 16)) = areg;
+        if (x_ld_ok) *(u32x4*)(Xs + buf * X_BYTES + tid * 16) = xreg;
+    };
+    f32x4 acc[5];
+#pragma unroll
+    for (int f = 0; f < 5; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    auto bias_acc = [&]() {
+        const T* e = (const T*)&areg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += to_f32(e[j]);
+    };
+    // transpose-read lane roles: lane L of a 16-lane group supplies row (L>>2) of the 4-row block, 4 columns (L&3)*4..+3
+    const int g = lane >> 4, rsub = (lane & 15) >> 2, cq = lane & 3;
+    int xoff[5];                                                        // byte offset of this lane's source for fragment f
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+        const int tap = 2 * f + (cq >> 1);
+        const int ky = tap / 3, kx = tap - ky * 3;
+        xoff[f] = (ky * BAND + kx) * 16 + (cq & 1) * 8;                 // (the 10th tap is redirected to the zero row below)
+    }
+    if (nsteps > 0) { gload(0); if (do_bias) bias_acc(); lstore(0); }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        const char* Ab = As + buf * A_BYTES;
+        const char* Xb = Xs + buf * X_BYTES;
+        const int cbyte = wave * 32 + cq * 8;
+        const short4v alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Ab + swz16<64>(8 * g + rsub, cbyte)));
+        const short4v ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Ab + swz16<64>(8 * g + 4 + rsub, cbyte)));
+        const u32x2 al = __builtin_bit_cast(u32x2, alo), ah = __builtin_bit_cast(u32x2, ahi);
+        const u32x4 af = {al.x, al.y, ah.x, ah.y};
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const bool dead = (2 * f + (cq >> 1)) >= 9;                 // the 10th "tap": read the zero row
+            const int r0 = dead ? 0 : (8 * g + rsub) * 16, r1 = dead ? 0 : (8 * g + 4 + rsub) * 16;
+            const int base = dead ? (3 * BAND) * 16 : xoff[f];
+            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Xb + base + r0));
+            const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Xb + base + r1));
+            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+            const u32x4 bf = {l2.x, l2.y, h2.x, h2.y};
+            if constexpr (DType<T>::id == DBX_F16)
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af), __builtin_bit_cast(f16x8, bf), acc[f], 0, 0, 0);
+            else
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[f], 0, 0, 0);
+        }
+        if (s + 1 < nsteps) { if (do_bias) bias_acc(); lstore(buf ^ 1); }
+        __syncthreads();
+    }
+    {   // slab [split][co (64)][tap (9)][ci_pad (8)]: fragment f column i = tap 2f + (i>>3), channel i&7
+        float* P = a.partial + ((long long)split * a.co_pad) * 9 * a.ci_pad;
+        const int co_b = wave * 16 + (lane >> 4) * 4, col = lane & 15;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const int tap = 2 * f + (col >> 3);
+            if (tap >= 9) continue;
+            const float v[4] = {acc[f].x, acc[f].y, acc[f].z, acc[f].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) P[((long long)(co_b + r) * 9 + tap) * a.ci_pad + (col & 7)] = v[r];
+        }
+    }
+    if (do_bias) {
+        __syncthreads();
+        float* red = (float*)smem;                       // [32 rows][64]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[ra * 64 + ca * 8 + j] = bsum[j];
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+            for (int r = 0; r < 32; ++r) sum += red[r * 64 + tid];
+            a.bpartial[(long long)split * a.co_pad + tid] = sum;
+        }
+    }
+}
+
 // dw[co][ci][tap] = sum_s partial[s][co][tap][ci], db[co] = sum_s bpartial[s][co].  Deterministic: 4 lanes own one output
 // element, lane g sums splits g, g+4, ... in ascending order, and the four partial sums are combined in the fixed order
 // ((s0+s1)+(s2+s3)).  Consecutive elements of a slab row map to consecutive 4-lane groups (coalesced 16-element reads).
@@ -417,7 +533,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps; long long Q; };
+struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8; long long Q; };
 
 static int wgrad_variant() {          // DBX_WGRAD_VARIANT=1: generic per-tap kernel everywhere (A/B testing)
     static int v = -1;
@@ -433,17 +549,20 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     // few-channel 3x3 layers: one workgroup accumulates all nine taps of a 64x64 tile
     p.alltaps = (dtype != DBX_F32 && kh == 3 && kw == 3 && wgrad_variant() != 1 && ((dz->c <= 128 && x->c <= 128) || wgrad_variant() == 2)) ? 1 : 0;
     if (p.alltaps) { p.bmc = 64; p.bnc = 64; }
+    // conv1_1: 8-channel (one chunk per pixel) input, 64 couts: (tap, channel) pairs form the GEMM N dimension
+    p.c8 = (p.alltaps && x->c * dbx_esize(dtype) == 16 && x->ld == x->c && dz->c == 64 && wgrad_variant() != 4) ? 1 : 0;
     p.co_pad = (dz->c + p.bmc - 1) / p.bmc * p.bmc;
-    p.ci_pad = (x->c + p.bnc - 1) / p.bnc * p.bnc;
-    p.tiles_co = p.co_pad / p.bmc; p.tiles_ci = p.ci_pad / p.bnc;
+    p.ci_pad = p.c8 ? 8 : (x->c + p.bnc - 1) / p.bnc * p.bnc;
+    p.tiles_co = p.co_pad / p.bmc; p.tiles_ci = p.c8 ? 1 : p.ci_pad / p.bnc;
     p.taps = kh * kw;
     p.Q = (long long)dz->n * (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad);
     const long long tiles = (long long)p.tiles_co * p.tiles_ci * (p.alltaps ? 1 : p.taps);
     const long long steps = (p.Q + 31) / 32;
-    long long splits = (1024 + tiles - 1) / tiles;            // aim for ~4 workgroups per CU (2 resident per CU)
+    // aim for ~4 workgroups per CU (2 resident per CU); the c8 kernel streams dz once: 2 workgroups per CU suffice
+    long long splits = ((p.c8 ? 512 : 1024) + tiles - 1) / tiles;
     const long long max_by_steps = steps / 16 > 0 ? steps / 16 : 1;   // at least 16 K-steps (512 rows) per split
     if (splits > max_by_steps) splits = max_by_steps;
-    if (splits > 256) splits = 256;
+    if (splits > (p.c8 ? 512 : 256)) splits = p.c8 ? 512 : 256;
     if (splits < 1) splits = 1;
     if (splits >= 8) splits = (splits + 7) / 8 * 8;           // XCD-aware workgroup mapping wants a multiple of 8
     long long sps = (steps + splits - 1) / splits;
@@ -479,7 +598,9 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.co_pad = p.co_pad; a.ci_pad = p.ci_pad; a.taps = p.taps; a.kw = kw; a.wp = x->w + 2 * x->pad;
     a.shift0 = x->pad - dz->pad - cpad;
     a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci; a.rows_per_split = p.rows_per_split; a.nsplit = p.splits;
-    if (p.alltaps) {
+    if (p.c8) {
+        if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wgrad3x3_c8_kernel<T>), dim3(p.splits), dim3(256), 0, s, a);
+    } else if (p.alltaps) {
         if constexpr (sizeof(T) == 2)
             hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), 0, s, a);
     } else {
