@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 
 
 
+
 // ------------------------------------------------------------------------------------------------ 3x3, all taps per workgroup
 // For layers with few channels (Cout, Cin <= 128 at 240x240 / 120x120) the per-tap tiling above is bound by refilling
 // LDS: every tap re-reads the same dz rows and a shifted copy of the same x rows (32 FLOP per byte filled).  Here one
