@@ -52,6 +52,7 @@ SIGNATURES = {
     'dbx_conv_packed_elems': (_I64, [_PC]),
     'dbx_conv_forward': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _VP, _I32, _VP]),
     'dbx_pack_weight': (C.c_int, [_I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
+    'dbx_fold_heads': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP]),
     'dbx_pack_multi': (C.c_int, [_I32, _VP, _I32, _I64, _VP]),
     'dbx_head2_dgrad': (C.c_int, [_I32, _PV, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I32, _PV, _VP, _I32, _VP]),
     'dbx_conv_wgrad_scratch_bytes': (_I64, [_I32, _PV, _PV, _I32, _I32]),

@@ -524,3 +524,29 @@ extern "C" int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, in
     DBX_REQUIRE(jobs && count > 0, "pack_multi: empty job table");
     DBX_DISPATCH_DTYPE(dtype, pack_multi_t, jobs, count, (long long)max_elems, (hipStream_t)stream);
 }
+
+// ---------------------------------------------------------------------------------------------- eval-mode head folding
+// The heads are Conv1x1(768->512) -> Dropout -> Conv1x1(512->k) with NO non-linearity (DenseBox.py:158-162); in eval
+// mode Dropout is the identity, so the pair is one linear map:  W = W2 W1  [k x 768],  b = W2 b1 + b2.
+// fp32 in, fp32 out; run once per weight version, not per image.
+__global__ void fold_heads_kernel(const float* __restrict__ w2, const float* __restrict__ b2, const float* __restrict__ w1,
+                                  const float* __restrict__ b1, int k, float* __restrict__ w, float* __restrict__ b) {
+    const int j = blockIdx.x;                       // output channel of this head
+    for (int c = threadIdx.x; c < 768; c += blockDim.x) {
+        float acc = 0.f;
+        for (int h = 0; h < 512; ++h) acc = fmaf(w2[j * 512 + h], w1[h * 768 + c], acc);
+        w[j * 768 + c] = acc;
+    }
+    if (threadIdx.x == 0) {
+        float acc = b2[j];
+        for (int h = 0; h < 512; ++h) acc = fmaf(w2[j * 512 + h], b1[h], acc);
+        b[j] = acc;
+    }
+}
+extern "C" int dbx_fold_heads(const float* w2, const float* b2, const float* w1, const float* b1, int32_t k, float* w_out,
+                              float* b_out, void* stream) {
+    DBX_REQUIRE(w2 && b2 && w1 && b1 && w_out && b_out && k >= 1, "fold_heads: bad arguments");
+    hipLaunchKernelGGL(fold_heads_kernel, dim3(k), dim3(256), 0, (hipStream_t)stream, w2, b2, w1, b1, k, w_out, b_out);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}

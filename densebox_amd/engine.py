@@ -262,6 +262,34 @@ class Engine:
         check(self.L.dbx_pack_multi(dt, ptr(tab[0]), tab[1], tab[2], stream_ptr()))
         self._wsig = sig
 
+    def _w_heads_folded(self, dt):
+        """Eval mode: each head's two 1x1 convs folded into one 768->k map; all heads stacked into ONE [ktot x 768] GEMM."""
+        heads = _HEADS[self.kind]
+        names = []
+        for s_, _ in heads:
+            names += ['conv5_1_%s.weight' % s_, 'conv5_1_%s.bias' % s_, 'conv5_2_%s.weight' % s_, 'conv5_2_%s.bias' % s_]
+        ps = [self._param(n) for n in names]
+        ver = tuple((p._version, p.data_ptr()) for p in ps)
+        ent = self.wcache.get(('folded', dt))
+        if ent is not None and ent[0] == ver:
+            return ent[1]
+        dev = ps[0].device
+        ktot = sum(k for _, k in heads)
+        wf = torch.empty((ktot, 768, 1, 1), dtype=torch.float32, device=dev)
+        bf = torch.zeros(64, dtype=torch.float32, device=dev)
+        o = 0
+        for i, (s_, k) in enumerate(heads):
+            w1, b1, w2, b2 = ps[4 * i:4 * i + 4]
+            check(self.L.dbx_fold_heads(ptr(w2.detach()), ptr(b2.detach()), ptr(w1.detach()), ptr(b1.detach()), k,
+                                        C.c_void_p(wf.data_ptr() + o * 768 * 4), C.c_void_p(bf.data_ptr() + o * 4),
+                                        stream_ptr()))
+            o += k
+        saved, self._defer = self._defer, None          # pack immediately (not part of the multi-tensor table)
+        wp = self._pack(dt, 0, wf, 64, 768, 1, 1)
+        self._defer = saved
+        self.wcache[('folded', dt)] = (ver, (wp, bf, ktot))
+        return wp, bf, ktot
+
     # ------------------------------------------------------------------ plumbing
     def plan(self, n, h, w, dt, device, train):
         key = (n, h, w, dt, train)
@@ -358,27 +386,38 @@ class Engine:
         conv3('conv4_4_1', 'a43', 'a44', 512, 512)
         check(L.dbx_upsample_bilinear(dt, C.byref(B['a44'].view()), C.byref(B['fusion'].view(0, 512)), s))
 
-        # heads: one GEMM 768 -> 512*nh over the shared fusion tensor, then 512 -> k per head
         heads = _HEADS[kind]
         nh = len(heads)
-        epi = _lib.EPI_BIAS
-        dm = None
-        P.drop_active = bool(train and self._dropout_p() > 0.0)
-        if P.drop_active:
-            dm = P.mask_ptr
-            self._fill_dropout(P, heads)
-            epi |= _lib.EPI_DROPMASK
-        self._conv(dt, B['fusion'].view(), B['hid'].view(), self._w_heads1(dt),
-                   self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh), 1, 1, 0, 768, 512 * nh, epi,
-                   dropmask=dm, dm_ld=512 * nh)
         outs = {}
         h4, w4 = P.h4, P.w4
-        for i, (stem, k) in enumerate(heads):
-            o = torch.empty((n, k, h4, w4), dtype=torch.float32, device=dev)
-            yv = View(C.c_void_p(o.data_ptr()), n, h4, w4, 0, k, 0, k)
-            self._conv(dt, B['hid'].view(512 * i, 512), yv, self._w_fwd(dt, 'conv5_2_' + stem, 512, 64),
-                       self._bias(['conv5_2_' + stem], 64), 1, 1, 0, 512, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
-            outs[stem] = o
+        if not train:
+            # eval: Dropout is the identity and the heads have no non-linearity -> one folded 768 -> sum(k) GEMM
+            wp, bf, ktot = self._w_heads_folded(dt)
+            big = torch.empty((n, ktot, h4, w4), dtype=torch.float32, device=dev)
+            yv = View(C.c_void_p(big.data_ptr()), n, h4, w4, 0, ktot, 0, ktot)
+            self._conv(dt, B['fusion'].view(), yv, wp, bf, 1, 1, 0, 768, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
+            o = 0
+            for stem, k in heads:
+                outs[stem] = big[:, o:o + k].contiguous()
+                o += k
+        else:
+            # train: one GEMM 768 -> 512*nh over the shared fusion tensor (dropout in its epilogue), then 512 -> k per head
+            epi = _lib.EPI_BIAS
+            dm = None
+            P.drop_active = bool(self._dropout_p() > 0.0)
+            if P.drop_active:
+                dm = P.mask_ptr
+                self._fill_dropout(P, heads)
+                epi |= _lib.EPI_DROPMASK
+            self._conv(dt, B['fusion'].view(), B['hid'].view(), self._w_heads1(dt),
+                       self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh), 1, 1, 0, 768, 512 * nh, epi,
+                       dropmask=dm, dm_ld=512 * nh)
+            for i, (stem, k) in enumerate(heads):
+                o = torch.empty((n, k, h4, w4), dtype=torch.float32, device=dev)
+                yv = View(C.c_void_p(o.data_ptr()), n, h4, w4, 0, k, 0, k)
+                self._conv(dt, B['hid'].view(512 * i, 512), yv, self._w_fwd(dt, 'conv5_2_' + stem, 512, 64),
+                           self._bias(['conv5_2_' + stem], 64), 1, 1, 0, 512, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
+                outs[stem] = o
         if kind != 'DenseBox':
             # refine branch: cat(landmarks, score) -> pool4 -> 3x3 -> 5x5 -> bilinear -> 1x1   (DenseBox.py:464-471)
             rin = B['rf_in'].view()

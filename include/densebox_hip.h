@@ -98,6 +98,11 @@ int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, int64_t max_e
 int dbx_head2_dgrad(int32_t dtype, const dbx_view* d_out, const float* const* w2, const int32_t* k, int32_t nh,
                     const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, void* stream);
 
+/* eval-mode folding of one head, Conv1x1(768->512) -> Dropout(identity) -> Conv1x1(512->k), into a single 768->k map
+ * (no non-linearity in between, DenseBox.py:158-162): w_out[k][768] = w2 w1, b_out[k] = w2 b1 + b2 (all fp32) */
+int dbx_fold_heads(const float* w2, const float* b2, const float* w1, const float* b1, int32_t k, float* w_out,
+                   float* b_out, void* stream);
+
 /* ------------------------------------------------------------------ weight gradient
  * dw[co][ci][ky][kx] (+)= sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-cpad,x+kx-cpad,ci]   (fp32 OIHW, DenseBox.py:2186)
  * db[co] = sum dz.   dz and x must live in frames of identical geometry (same n,h,w,pad).
