@@ -550,3 +550,45 @@ extern "C" int dbx_fold_heads(const float* w2, const float* b2, const float* w1,
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- uint8 HWC image -> network input
+// torchvision's ToTensor + Normalize of the reference datasets (DenseBox.py:766-772, :3613-3619) fused with the layout
+// change: y[n,py,px,c] = ((u8 / 255) - mean[c]) / std[c] in fp32 (true divisions, like ATen), rounded to the compute
+// dtype, channels 3.. of the framed view zero-filled.  12 bytes in, 16 bytes out per pixel.
+template <typename T>
+__global__ void u8hwc_to_framed_kernel(const unsigned char* __restrict__ x, FrameGeo y, float m0, float m1, float m2, float s0,
+                                       float s1, float s2) {
+    constexpr int V = Vec<T>::N;
+    const int cg = y.c / V;
+    const int64_t total = (int64_t)y.n * y.h * y.w;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % y.w);
+        const int py = (int)((i / y.w) % y.h);
+        const int n = (int)(i / ((int64_t)y.w * y.h));
+        const unsigned char* p = x + i * 3;
+        float v[3];
+        v[0] = ((float)p[0] / 255.0f - m0) / s0;
+        v[1] = ((float)p[1] / 255.0f - m1) / s1;
+        v[2] = ((float)p[2] / 255.0f - m2) / s2;
+        T* dst = (T*)y.base + geo_pix(y, n, py, px);
+        for (int g = 0; g < cg; ++g) {
+            float o[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) { const int c = g * V + j; o[j] = c < 3 ? v[c] : 0.f; }
+            store_vec<T>(dst + g * V, o);
+        }
+    }
+}
+template <typename T> static int u8hwc_to_framed_t(const uint8_t* x, const dbx_view* y, const float* mean, const float* stdv, hipStream_t s) {
+    VIEW_VEC_CHECK(T, y, "u8hwc_to_framed");
+    DBX_REQUIRE(y->c >= 3 && mean && stdv, "u8hwc_to_framed: need >= 3 channels and mean/std");
+    const int64_t total = (int64_t)y->n * y->h * y->w;
+    hipLaunchKernelGGL(u8hwc_to_framed_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, x, make_geo<T>(y), mean[0], mean[1], mean[2],
+                       stdv[0], stdv[1], stdv[2]);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_u8hwc_to_framed(int32_t dtype, const uint8_t* x_nhwc, const dbx_view* y, const float* mean3, const float* std3,
+                                   void* stream) {
+    DBX_DISPATCH_DTYPE(dtype, u8hwc_to_framed_t, x_nhwc, y, mean3, std3, (hipStream_t)stream);
+}

@@ -346,10 +346,15 @@ class Engine:
 
     def forward_raw(self, X, train):
         """Runs the network; returns dict name -> fp32 NCHW tensor.  Activations stay in the plan's workspace."""
-        assert X.dim() == 4 and X.size(1) == 3, 'input must be [N,3,H,W]'
+        u8 = X.dtype == torch.uint8
+        if u8:
+            assert X.dim() == 4 and X.size(3) == 3, 'uint8 input must be [N,H,W,3] (HWC, RGB)'
+            n, h, w, _ = X.shape
+        else:
+            assert X.dim() == 4 and X.size(1) == 3, 'input must be [N,3,H,W]'
+            n, _, h, w = X.shape
         L, kind = self.L, self.kind
         dt = _lib.DTYPE_ID[self.net.compute_dtype]
-        n, _, h, w = X.shape
         assert h >= 8 and w >= 8, 'input smaller than the /8 stride'
         if kind != 'DenseBox':
             assert h // 8 >= 7 and w // 8 >= 7, 'refine branch (3x3 + 5x5 un-padded convs) needs H/8, W/8 >= 7'
@@ -359,8 +364,15 @@ class Engine:
         B = P.B
         s = stream_ptr()
         self._prepare_weights(dt, train, P)
-        Xf = X.detach().to(torch.float32).contiguous()
-        check(L.dbx_nchw_to_framed(dt, ptr(Xf), 3, C.byref(B['x0'].view()), s))
+        if u8:
+            # raw patches: ToTensor + ImageNet Normalize (DenseBox.py:766-772) fused into the layout kernel
+            from .data import IMAGENET_MEAN, IMAGENET_STD
+            Xc = X.detach().contiguous()
+            check(L.dbx_u8hwc_to_framed(dt, ptr(Xc), C.byref(B['x0'].view()), (C.c_float * 3)(*IMAGENET_MEAN),
+                                        (C.c_float * 3)(*IMAGENET_STD), s))
+        else:
+            Xf = X.detach().to(torch.float32).contiguous()
+            check(L.dbx_nchw_to_framed(dt, ptr(Xf), 3, C.byref(B['x0'].view()), s))
         RELU = _lib.EPI_BIAS | _lib.EPI_RELU
 
         def conv3(stem, src, dst, cin, cout, dst_view=None):

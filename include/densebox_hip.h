@@ -122,6 +122,10 @@ int dbx_conv_wgrad(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t
  */
 /* x_nchw has c_src channels; channels c_src..y->c-1 of the framed view are written as 0 (also used for dL/dout) */
 int dbx_nchw_to_framed(int32_t dtype, const float* x_nchw, int32_t c_src, const dbx_view* y, void* stream);
+/* uint8 [N][H][W][3] images -> framed network input: ((u8/255) - mean[c]) / std[c] (fp32, true divisions), i.e. torchvision
+ * ToTensor + Normalize of the reference datasets (DenseBox.py:766-772) fused with the layout change.  mean3/std3: HOST floats */
+int dbx_u8hwc_to_framed(int32_t dtype, const uint8_t* x_nhwc, const dbx_view* y, const float* mean3, const float* std3,
+                        void* stream);
 /* scatter c_src fp32 NCHW planes into channels [c_dst_off, c_dst_off+c_src) of y; other channels untouched
  * (builds cat(landmarks, score), DenseBox.py:464 / :729) */
 int dbx_nchw_to_framed_ch(int32_t dtype, const float* x_nchw, int32_t c_src, const dbx_view* y, int32_t c_dst_off,

@@ -405,3 +405,21 @@ def nms(dets, thresh=0.4):
             ovr = inter / (areas[i] + areas[rest] - inter)
         order = rest[ovr <= thresh]
     return keep
+
+
+# ============================================================================ input side
+def parse_label_name(name, fields=12):
+    """The 12- (or 4-) integer file-name label of the reference datasets (DenseBox.py:787-860, :928-970, :1038-1052):
+    ints / 4.0 -> float32; for the 12-field DenseBoxDataset form an all-zero label is a negative patch."""
+    import re
+    m = re.match('.*_label_' + '_'.join(['([0-9]+)'] * fields) + ('.*' if fields == 12 else ''), name)
+    vals = np.array([float(m.group(i)) for i in range(1, fields + 1)])
+    return (vals / 4.0).astype(np.float32), bool(np.all(vals == 0.0))
+
+
+def normalize_u8(u8_nhwc):
+    """torchvision ToTensor + Normalize(mean, std) (DenseBox.py:766-772): uint8 [N,H,W,3] -> fp32 NCHW."""
+    x = torch.as_tensor(u8_nhwc).permute(0, 3, 1, 2).to(torch.float32).div(255)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return (x - mean) / std

@@ -495,10 +495,48 @@ def gen_decode():
     print('decode.npz', d['nms_keep_04'], len(d['nms_big_keep']))
 
 
+# ----------------------------------------------------------------------------- E. dataset label parsing
+def gen_datasets():
+    """File-name labels as the reference's Dataset constructors parse them (DenseBox.py:784-860, :927-970, :1038-1052).
+    Only __init__ runs (it lists the directory and parses names); the files are empty."""
+    import tempfile
+    names12 = [
+        'img001_label_80_88_160_120_78_86_162_87_161_122_79_121.jpg',
+        'neg_7_label_0_0_0_0_0_0_0_0_0_0_0_0.jpg',
+        'x_label_33_57_131_95_31_55_133_58_130_97_35_96_extra.png',
+        'plate_00012_label_0_40_200_100_8_40_200_42_198_100_9_99.jpg',
+        'a_b_label_150_30_230_70_150_30_239_31_238_70_151_69.jpeg',
+        'p_label_1_2_3_4_5_6_7_8_9_10_11_12.jpg',
+    ]
+    names4 = ['q_label_12_34_56_78.jpg', 'r2_label_0_16_239_240.jpg'] + names12[:2]
+    d = {}
+    with tempfile.TemporaryDirectory() as root:
+        for n in names12:
+            open(os.path.join(root, n), 'w').close()
+        ds = R.DenseBoxDataset(root=root, transform=None, size=(240, 240))
+        order = [os.path.split(p)[1] for p in ds.imgs_path]
+        d['db_names'] = np.array(order)
+        d['db_bbox'] = np.stack([t2n(t) for t in ds.bboxes])
+        d['db_vert'] = np.stack([t2n(t) for t in ds.vertices])
+        d['db_lab'] = np.stack([t2n(t) for t in ds.labels])
+        lm = R.LPPatchLM_Online(root=root, transform=None, size=(240, 240))
+        d['lm_names'] = np.array([os.path.split(p)[1] for p in lm.imgs_path])
+        d['lm_bbox'] = np.stack([t2n(t) for t in lm.bboxes])
+        d['lm_vert'] = np.stack([t2n(t) for t in lm.vertices])
+    with tempfile.TemporaryDirectory() as root:
+        for n in names4:
+            open(os.path.join(root, n), 'w').close()
+        lp = R.LPPatch_Online(root=root, transform=None, size=(240, 240))
+        d['lp_names'] = np.array([os.path.split(p)[1] for p in lp.imgs_path])
+        d['lp_bbox'] = np.stack([t2n(t) for t in lp.labels])
+    np.savez_compressed(os.path.join(OUT, 'datasets.npz'), **d)
+    print('datasets.npz', d['db_bbox'].shape, d['lm_vert'].shape, d['lp_bbox'].shape)
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['labels', 'decode', 'nets', 'train']
+    which = sys.argv[1:] or ['labels', 'decode', 'nets', 'train', 'datasets']
     for w in which:
-        {'labels': gen_labels, 'decode': gen_decode, 'nets': gen_nets, 'train': gen_train}[w]()
+        {'labels': gen_labels, 'decode': gen_decode, 'nets': gen_nets, 'train': gen_train, 'datasets': gen_datasets}[w]()
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('total fixture bytes', sz)
