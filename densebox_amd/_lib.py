@@ -13,7 +13,7 @@ F16, BF16, F32 = 0, 1, 2
 DTYPE_ID = {'f16': F16, 'bf16': BF16, 'f32': F32}
 ESIZE = {F16: 2, BF16: 2, F32: 4}
 
-EPI_BIAS, EPI_RELU, EPI_GATE, EPI_DROPMASK, EPI_ACCUM, EPI_F32_NCHW = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_RELU, EPI_GATE, EPI_DROPMASK, EPI_ACCUM, EPI_F32_NCHW, EPI_DROPHASH = 1, 2, 4, 8, 16, 32, 64
 
 
 class View(C.Structure):
@@ -23,7 +23,7 @@ class View(C.Structure):
 
 class ConvDesc(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('kh', C.c_int32), ('kw', C.c_int32), ('cpad', C.c_int32),
-                ('cin_pad', C.c_int32), ('cout_pad', C.c_int32), ('epilogue', C.c_int32)]
+                ('cin_pad', C.c_int32), ('cout_pad', C.c_int32), ('epilogue', C.c_int32), ('drop_seed', C.c_uint32)]
 
 
 class LossDesc(C.Structure):
@@ -54,7 +54,7 @@ SIGNATURES = {
     'dbx_pack_weight': (C.c_int, [_I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
     'dbx_fold_heads': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP]),
     'dbx_pack_multi': (C.c_int, [_I32, _VP, _I32, _I64, _VP]),
-    'dbx_head2_dgrad': (C.c_int, [_I32, _PV, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I32, _PV, _VP, _I32, _VP]),
+    'dbx_head2_dgrad': (C.c_int, [_I32, _PV, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I32, _PV, _VP, _I32, _I32, C.c_uint32, _VP]),
     'dbx_conv_wgrad_scratch_bytes': (_I64, [_I32, _PV, _PV, _I32, _I32]),
     'dbx_conv_wgrad': (C.c_int, [_I32, _PV, _PV, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _VP]),
     'dbx_nchw_to_framed': (C.c_int, [_I32, _VP, _I32, _PV, _VP]),
@@ -66,7 +66,6 @@ SIGNATURES = {
     'dbx_maxpool2x2_bwd': (C.c_int, [_I32, _PV, _PV, _PV, _I32, _I32, _VP]),
     'dbx_upsample_bilinear': (C.c_int, [_I32, _PV, _PV, _VP]),
     'dbx_upsample_bilinear_bwd': (C.c_int, [_I32, _PV, _PV, _PV, _VP]),
-    'dbx_dropout_mask': (C.c_int, [_VP, _I64, C.c_uint64, _VP]),
     'dbx_loss_forward_backward': (C.c_int, [C.POINTER(LossDesc), C.POINTER(LossIO), _VP, _VP]),
     'dbx_count_positives': (C.c_int, [_VP, _VP, _I32, _VP, _VP]),
     'dbx_init_score_map': (C.c_int, [_VP, _VP, _I32, _VP, _VP]),

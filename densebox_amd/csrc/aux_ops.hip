@@ -351,35 +351,6 @@ extern "C" int dbx_nchw_to_framed_ch(int32_t dtype, const float* x_nchw, int32_t
     DBX_DISPATCH_DTYPE(dtype, nchw_to_framed_ch_t, x_nchw, c_src, y, c_dst_off, (hipStream_t)stream);
 }
 
-// ---------------------------------------------------------------------------------------------- dropout mask (p = 0.5)
-// Counter-based: bit j of splitmix64(seed + word index).  Device RNG cannot reproduce torch's CPU stream
-// (SURVEY.md 8c), so parity tests inject masks instead; this generator is the training-mode default.
-__device__ __forceinline__ unsigned long long splitmix64(unsigned long long z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__global__ void dropout_mask_kernel(unsigned char* __restrict__ m, int64_t nbytes, unsigned long long seed) {
-    const int64_t nvec = nbytes / 16;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-        const unsigned long long r = splitmix64(seed * 0x100000001B3ull + (unsigned long long)i);
-        u32x4 o;
-        o.x = (unsigned)(r & 1) | (unsigned)((r >> 1) & 1) << 8 | (unsigned)((r >> 2) & 1) << 16 | (unsigned)((r >> 3) & 1) << 24;
-        o.y = (unsigned)((r >> 4) & 1) | (unsigned)((r >> 5) & 1) << 8 | (unsigned)((r >> 6) & 1) << 16 | (unsigned)((r >> 7) & 1) << 24;
-        o.z = (unsigned)((r >> 8) & 1) | (unsigned)((r >> 9) & 1) << 8 | (unsigned)((r >> 10) & 1) << 16 | (unsigned)((r >> 11) & 1) << 24;
-        o.w = (unsigned)((r >> 12) & 1) | (unsigned)((r >> 13) & 1) << 8 | (unsigned)((r >> 14) & 1) << 16 | (unsigned)((r >> 15) & 1) << 24;
-        *(u32x4*)(m + i * 16) = o;
-    }
-}
-extern "C" int dbx_dropout_mask(uint8_t* mask, int64_t nbytes, uint64_t seed, void* stream) {
-    DBX_REQUIRE(nbytes % 16 == 0 && ((size_t)mask % 16) == 0, "dropout_mask: 16-byte granularity");
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(nbytes / 16)), dim3(256), 0, (hipStream_t)stream, mask, nbytes,
-                       (unsigned long long)seed);
-    DBX_LAUNCH_CHECK();
-    return DBX_OK;
-}
-
 // ---------------------------------------------------------------------------------------------- channel-slice accumulate
 // dst[n,y,x, c_dst_off + j] += src[n,y,x, c_src_off + j], j < n_ch.  Routes the refine branch's input gradient
 // (d cat(landmarks, score), DenseBox.py:464) back onto the landmark / score head gradients.
@@ -419,7 +390,8 @@ struct Head2Args { const float* w2[4]; int k[4]; int nh; int slot; };
 
 template <typename T>
 __global__ __launch_bounds__(512) void head2_dgrad_kernel(FrameGeo dout, Head2Args ha, FrameGeo dhid,
-                                                          const unsigned char* __restrict__ mask, int mask_ld) {
+                                                          const unsigned char* __restrict__ mask, int mask_ld, int use_hash,
+                                                          unsigned drop_seed) {
     constexpr int V = Vec<T>::N;                  // channels per lane
     constexpr int LPH = 512 / V;                  // lanes per (pixel, head): 64 for 16-bit types, 128 for f32
     const int lph_all = LPH * ha.nh;              // lanes per pixel
@@ -464,6 +436,13 @@ __global__ __launch_bounds__(512) void head2_dgrad_kernel(FrameGeo dout, Head2Ar
                 if constexpr (V == 8) *(u32x2*)mb = *(const u32x2*)mk; else *(unsigned int*)mb = *(const unsigned int*)mk;
 #pragma unroll
                 for (int i = 0; i < V; ++i) o[i] = mb[i] ? o[i] * 2.f : 0.f;
+            } else if (use_hash) {                      // same keep bits as the forward epilogue (DBX_EPI_DROPHASH)
+#pragma unroll
+                for (int q = 0; q < V / 4; ++q) {
+                    const unsigned kb = dbx_drop_bits4(drop_seed, (unsigned)m, (unsigned)(hd * 512 + c0) / 4 + q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[4 * q + i] = (kb >> i & 1u) ? o[4 * q + i] * 2.f : 0.f;
+                }
             }
             store_vec<T>((T*)dhid.base + geo_pix(dhid, n, py, px) + hd * 512 + c0, o);
         }
@@ -471,7 +450,7 @@ __global__ __launch_bounds__(512) void head2_dgrad_kernel(FrameGeo dout, Head2Ar
 }
 template <typename T>
 static int head2_dgrad_t(const dbx_view* dout, const float* const* w2, const int32_t* k, int nh, const dbx_view* dhid,
-                         const uint8_t* mask, int mask_ld, hipStream_t s) {
+                         const uint8_t* mask, int mask_ld, int use_hash, unsigned drop_seed, hipStream_t s) {
     VIEW_VEC_CHECK(T, dhid, "head2_dgrad d_hid");
     DBX_REQUIRE(nh >= 1 && nh <= 4 && dhid->c == 512 * nh && dout->c % nh == 0 && dout->c / nh >= 8, "head2_dgrad: nh in 1..4, d_hid of 512*nh channels, d_out of nh slots >= 8 channels");
     DBX_REQUIRE(dout->n == dhid->n && dout->h == dhid->h && dout->w == dhid->w, "head2_dgrad: shape mismatch");
@@ -483,14 +462,15 @@ static int head2_dgrad_t(const dbx_view* dout, const float* const* w2, const int
     const int lph_all = (512 / Vec<T>::N) * nh;
     const int threads = lph_all <= 256 ? 256 : 512;
     int blocks = dhid->n * dhid->h; blocks = blocks > 8192 ? 8192 : blocks;
-    hipLaunchKernelGGL(head2_dgrad_kernel<T>, dim3(blocks), dim3(threads), 0, s, make_geo<T>(dout), ha, make_geo<T>(dhid), mask, mask_ld);
+    hipLaunchKernelGGL(head2_dgrad_kernel<T>, dim3(blocks), dim3(threads), 0, s, make_geo<T>(dout), ha, make_geo<T>(dhid), mask, mask_ld, use_hash, drop_seed);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }
 extern "C" int dbx_head2_dgrad(int32_t dtype, const dbx_view* d_out, const float* const* w2, const int32_t* k, int32_t nh,
-                               const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, void* stream) {
+                               const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash,
+                               uint32_t drop_seed, void* stream) {
     if (!d_out || !w2 || !k || !d_hid) { dbx_set_error("head2_dgrad: null argument"); return DBX_ERR_ARG; }
-    DBX_DISPATCH_DTYPE(dtype, head2_dgrad_t, d_out, w2, k, nh, d_hid, dropmask, dropmask_ld, (hipStream_t)stream);
+    DBX_DISPATCH_DTYPE(dtype, head2_dgrad_t, d_out, w2, k, nh, d_hid, dropmask, dropmask_ld, use_hash, (unsigned)drop_seed, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------- multi-tensor weight packing

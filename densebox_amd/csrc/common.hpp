@@ -78,6 +78,14 @@ __device__ __forceinline__ size_t geo_pix(const FrameGeo& g, int n, int y, int x
     return ((size_t)(n * g.hp + y + g.pad) * g.wp + (x + g.pad)) * (size_t)g.ld;
 }
 
+// Counter-based dropout keep bits (p = 0.5): bit j of the result is the keep bit of channel 4*c4 + j of pixel m.
+// lowbias32 finaliser over (seed, pixel, channel group): stateless, so forward and backward regenerate identical masks.
+__device__ __forceinline__ unsigned dbx_drop_bits4(unsigned seed, unsigned m, unsigned c4) {
+    unsigned x = seed ^ (m * 0x9E3779B1u) ^ (c4 * 0x85EBCA77u);
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
 #define DBX_DISPATCH_DTYPE(dtype, FN, ...)                          \
     switch (dtype) {                                                \
         case DBX_F16: return FN<_Float16>(__VA_ARGS__);             \

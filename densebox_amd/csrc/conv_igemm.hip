@@ -38,6 +38,7 @@ struct ConvArgs {
     int nblocks;
     int epi;
     int dm_ld;
+    unsigned drop_seed;
 };
 
 template <typename T> struct Mma;
@@ -99,6 +100,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI
                 const unsigned int mk = *(const unsigned int*)(a.dropmask + (size_t)m * a.dm_ld + c);
                 v.x = (mk & 0xffu) ? v.x * 2.f : 0.f; v.y = (mk & 0xff00u) ? v.y * 2.f : 0.f;
                 v.z = (mk & 0xff0000u) ? v.z * 2.f : 0.f; v.w = (mk & 0xff000000u) ? v.w * 2.f : 0.f;
+            }
+            if (epi & DBX_EPI_DROPHASH) {
+                const unsigned kb = dbx_drop_bits4(a.drop_seed, (unsigned)m, (unsigned)c >> 2);
+                v.x = (kb & 1u) ? v.x * 2.f : 0.f; v.y = (kb & 2u) ? v.y * 2.f : 0.f;
+                v.z = (kb & 4u) ? v.z * 2.f : 0.f; v.w = (kb & 8u) ? v.w * 2.f : 0.f;
             }
             if (epi & DBX_EPI_F32_NCHW) {
                 float* o = (float*)a.y + ((size_t)n * a.cout_valid + c) * a.HoWo + r;
@@ -659,12 +665,12 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.ktot_bytes = (int)(packed_k_elems(d) * ES);
     a.ksteps = a.ktot_bytes / 128;
     a.cout_valid = y->c;
-    a.epi = d->epilogue; a.dm_ld = dm_ld;
+    a.epi = d->epilogue; a.dm_ld = dm_ld; a.drop_seed = d->drop_seed;
     DBX_REQUIRE(a.M > 0 && (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < (int64_t)1 << 40, "conv: empty or oversized input");
 
     // 3x3 / pad 1 on congruent frames (x.pad == 1), 16-bit, plain NHWC epilogue: the band kernel over the linearised frame
     if (!smallc && sizeof(T) == 2 && conv_variant() == 0 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 &&
-        !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK)) && (d->cin_pad * ES) % 64 == 0 && y->c % 64 == 0) {
+        !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK | DBX_EPI_DROPHASH)) && (d->cin_pad * ES) % 64 == 0 && y->c % 64 == 0) {
         const long long Q = (long long)x->n * a.x_hp * a.x_wp;
         const int tiles256 = (int)((Q + 255) / 256), tiles512 = (int)((Q + 511) / 512);
         const bool tall = conv_variant() != 4 && tiles512 >= 1024;      // enough work for >= 4 tall tiles per CU
@@ -738,7 +744,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int co, int ci, 
 template <typename T>
 static int pack_weight_t(int mode, const float* w, int co, int ci, int kh, int kw, void* wp, int rows_pad, int cin_pad,
                          int row_off, int k_off, hipStream_t s) {
-    dbx_conv_desc d; d.dtype = DType<T>::id; d.kh = kh; d.kw = kw; d.cin_pad = cin_pad; d.cout_pad = rows_pad;
+    dbx_conv_desc d; d.dtype = DType<T>::id; d.kh = kh; d.kw = kw; d.cin_pad = cin_pad; d.cout_pad = rows_pad; d.drop_seed = 0;
     const int64_t ktot = packed_k_elems(&d);
     const int rows = mode == 0 ? co : ci, cols = mode == 0 ? ci : co;
     DBX_REQUIRE(row_off + rows <= rows_pad && k_off + cols <= cin_pad, "pack_weight: slice out of range");

@@ -99,17 +99,16 @@ class Plan:
             off += b.guard
             b.off = off
             off += _align(b.bytes) + b.guard
-        self.mask_off = off
-        self.mask_bytes = _align(n * h4 * w4 * 512 * nh) if train else 0
-        off += self.mask_bytes
         self.total = off
+        self.drop_active = self.drop_hash = False
+        self.drop_seed = 0
+        self.mask_buf = None
         self.ws = torch.zeros(off, dtype=torch.uint8, device=device)
         base = self.ws.data_ptr()
         assert base % 256 == 0
         for b in B.values():
             b.base = base + b.off
         self.B = B
-        self.mask_ptr = base + self.mask_off
 
 
 class Engine:
@@ -159,7 +158,7 @@ class Engine:
 
     def _pack(self, dt, mode, w, rows_pad, cin_pad, kh, kw, out=None, row_off=0, k_off=0):
         """fp32 OIHW parameter -> packed compute-dtype matrix [rows_pad][ktot]."""
-        d = ConvDesc(dt, kh, kw, 0, cin_pad, rows_pad, 0)
+        d = ConvDesc(dt, kh, kw, 0, cin_pad, rows_pad, 0, 0)
         elems = self.L.dbx_conv_packed_elems(C.byref(d))
         if out is None:
             out = torch.zeros(elems * _lib.ESIZE[dt], dtype=torch.uint8, device=w.device)
@@ -300,8 +299,8 @@ class Engine:
         return p
 
     def _conv(self, dt, x, y, wpk, bias, kh, kw, cpad, cin_pad, cout_pad, epi, gate=None, dropmask=None, dm_ld=0,
-              alg_ci=None):
-        d = ConvDesc(dt, kh, kw, cpad, cin_pad, cout_pad, epi)
+              alg_ci=None, drop_seed=0):
+        d = ConvDesc(dt, kh, kw, cpad, cin_pad, cout_pad, epi, drop_seed)
         prof = self.profile
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -417,13 +416,18 @@ class Engine:
             epi = _lib.EPI_BIAS
             dm = None
             P.drop_active = bool(self._dropout_p() > 0.0)
-            if P.drop_active:
-                dm = P.mask_ptr
-                self._fill_dropout(P, heads)
+            P.drop_hash = P.drop_active and self.net.dropout_masks is None
+            if P.drop_hash:
+                # keep bits come from a counter-based hash of (seed, pixel, channel): nothing to store or re-read
+                self._seed = (getattr(self, '_seed', 0x5eed) * 1664525 + 1013904223) & 0xffffffff
+                P.drop_seed = self._seed
+                epi |= _lib.EPI_DROPHASH
+            elif P.drop_active:
+                dm = self._fill_dropout(P, heads)       # injected masks (parity tests)
                 epi |= _lib.EPI_DROPMASK
             self._conv(dt, B['fusion'].view(), B['hid'].view(), self._w_heads1(dt),
                        self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh), 1, 1, 0, 768, 512 * nh, epi,
-                       dropmask=dm, dm_ld=512 * nh)
+                       dropmask=dm, dm_ld=512 * nh, drop_seed=P.drop_seed if P.drop_hash else 0)
             for i, (stem, k) in enumerate(heads):
                 o = torch.empty((n, k, h4, w4), dtype=torch.float32, device=dev)
                 yv = View(C.c_void_p(o.data_ptr()), n, h4, w4, 0, k, 0, k)
@@ -457,19 +461,15 @@ class Engine:
         return p
 
     def _fill_dropout(self, P, heads):
-        """Training-mode keep-masks: injected (parity) or drawn by the device RNG."""
+        """Injected keep-masks {head: [N,512,h,w]} (NCHW like the reference's Dropout input) -> uint8 [M][512*nh] buffer."""
         nh = len(heads)
         inj = self.net.dropout_masks
-        nbytes = P.n * P.h4 * P.w4 * 512 * nh
-        if inj is not None:
-            # injected masks arrive as {head: uint8/bool/float [N,512,h,w]} (NCHW like the reference's Dropout input)
-            m = torch.empty((P.n, P.h4, P.w4, nh, 512), dtype=torch.uint8, device=P.ws.device)
-            for i, (stem, _) in enumerate(heads):
-                m[:, :, :, i, :] = inj[stem].to(P.ws.device).permute(0, 2, 3, 1).to(torch.uint8)
-            P.ws[P.mask_off:P.mask_off + nbytes].copy_(m.reshape(-1))
-        else:
-            self._seed = getattr(self, '_seed', 0x5eed) + 1
-            check(self.L.dbx_dropout_mask(C.c_void_p(P.mask_ptr), _align(nbytes, 16), self._seed, stream_ptr()))
+        dev = P.ws.device
+        m = torch.empty((P.n, P.h4, P.w4, nh, 512), dtype=torch.uint8, device=dev)
+        for i, (stem, _) in enumerate(heads):
+            m[:, :, :, i, :] = inj[stem].to(dev).permute(0, 2, 3, 1).to(torch.uint8)
+        P.mask_buf = m                              # kept alive until the backward pass has used it
+        return m.data_ptr()
 
     # debugging / tests: read an activation back as fp32 NCHW
     def read_activation(self, name, c_off=0, c=None):
@@ -586,7 +586,8 @@ class Engine:
         w2s = [self._param('conv5_2_%s.weight' % st).detach() for st, _ in heads]      # fp32 [k,512,1,1]
         check(L.dbx_head2_dgrad(dt, C.byref(B['d_out'].view()), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]),
                                 (C.c_int32 * nh)(*[k for _, k in heads]), nh, C.byref(B['d_hid'].view()),
-                                C.c_void_p(P.mask_ptr) if P.drop_active else None, 512 * nh, s))
+                                C.c_void_p(P.mask_buf.data_ptr()) if (P.drop_active and not P.drop_hash) else None, 512 * nh,
+                                1 if P.drop_hash else 0, P.drop_seed if P.drop_hash else 0, s))
         w1n = ['conv5_1_%s.weight' % st for st, _ in heads]
         b1n = ['conv5_1_%s.bias' % st for st, _ in heads]
         if sink is not None:           # the heads' conv5_1 gradients are adjacent in the flat buffer (grad_order)

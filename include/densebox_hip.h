@@ -60,9 +60,11 @@ enum dbx_epilogue {
     DBX_EPI_BIAS     = 1,   /* + bias[co] (fp32) */
     DBX_EPI_RELU     = 2,   /* max(.,0) */
     DBX_EPI_GATE     = 4,   /* zero where gate[n,oy,ox,co] <= 0 (ReLU backward; gate = forward activation) */
-    DBX_EPI_DROPMASK = 8,   /* * 2 * mask[m][co] (uint8 {0,1}, unframed [M][c]) -- nn.Dropout(0.5) train mode */
+    DBX_EPI_DROPMASK = 8,   /* * 2 * mask[m][co] (uint8 {0,1}, unframed [M][c]) -- nn.Dropout(0.5) with a caller-supplied mask */
     DBX_EPI_ACCUM    = 16,  /* y += result (dtype of y) */
-    DBX_EPI_F32_NCHW = 32   /* write fp32 NCHW [N][cv][Ho][Wo] (cv = y->c valid channels) instead of framed NHWC */
+    DBX_EPI_F32_NCHW = 32,  /* write fp32 NCHW [N][cv][Ho][Wo] (cv = y->c valid channels) instead of framed NHWC */
+    DBX_EPI_DROPHASH = 64   /* nn.Dropout(0.5) with the keep bit of element (m, co) = dbx_drop_keep(desc.drop_seed, m, co): no mask
+                               buffer; dbx_head2_dgrad regenerates the same bits in backward */
 };
 
 typedef struct dbx_conv_desc {
@@ -72,6 +74,7 @@ typedef struct dbx_conv_desc {
     int32_t cin_pad;       /* channels per tap in the packed weight (multiple of 16 bytes worth) */
     int32_t cout_pad;      /* rows of the packed weight (multiple of 64) */
     int32_t epilogue;      /* OR of dbx_epilogue */
+    uint32_t drop_seed;    /* DBX_EPI_DROPHASH: per-step seed of the counter-based keep mask */
 } dbx_conv_desc;
 
 /* packed weight: [cout_pad][ktot] elements, ktot = roundup(kh*kw*cin_pad*esize, 128 B)/esize, k = tap*cin_pad + ci */
@@ -93,10 +96,12 @@ int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw, int32_t co
 int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, void* stream);
 
 /* heads: data gradient of the nh (<= 4) Conv1x1(512->k_h) layers behind Dropout in one rank-k streaming pass:
- * d_hid[m, 512h+c] = (dropmask ? 2*mask[m,512h+c] : 1) * sum_{j<k_h} d_out[m, slot*h + j] * w2[h][j][c]
+ * d_hid[m, 512h+c] = keep(m, 512h+c) * sum_{j<k_h} d_out[m, slot*h + j] * w2[h][j][c];  keep = 2*mask[..] (dropmask buffer),
+ * 2*hash bit (use_hash, same bits as DBX_EPI_DROPHASH with drop_seed) or 1 (neither)
  * d_out: nh equal channel slots (>= 8 each); w2[h]: fp32 [k_h][512]; w2 / k are HOST arrays (DenseBox.py:158-162) */
 int dbx_head2_dgrad(int32_t dtype, const dbx_view* d_out, const float* const* w2, const int32_t* k, int32_t nh,
-                    const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, void* stream);
+                    const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash, uint32_t drop_seed,
+                    void* stream);
 
 /* eval-mode folding of one head, Conv1x1(768->512) -> Dropout(identity) -> Conv1x1(512->k), into a single 768->k map
  * (no non-linearity in between, DenseBox.py:158-162): w_out[k][768] = w2 w1, b_out[k] = w2 b1 + b2 (all fp32) */
@@ -134,8 +139,6 @@ int dbx_framed_to_nchw_f32(int32_t dtype, const dbx_view* x, float* y_nchw, void
 /* dst[..., c_dst_off+j] += src[..., c_src_off+j], j < n_ch (gradient of the channel concat at DenseBox.py:464) */
 int dbx_framed_add_ch(int32_t dtype, const dbx_view* src, int32_t c_src_off, int32_t n_ch, const dbx_view* dst,
                       int32_t c_dst_off, void* stream);
-/* nn.Dropout(p=0.5) keep-mask bytes {0,1} from a counter-based device RNG (DenseBox.py:160); nbytes % 16 == 0 */
-int dbx_dropout_mask(uint8_t* mask, int64_t nbytes, uint64_t seed, void* stream);
 int dbx_maxpool2x2(int32_t dtype, const dbx_view* x, const dbx_view* y, void* stream);
 /* x = pre-pool activation, dy = grad of the pooled map, dx = grad of the pre-pool map (same frame as x) */
 int dbx_maxpool2x2_bwd(int32_t dtype, const dbx_view* x, const dbx_view* dy, const dbx_view* dx,

@@ -169,3 +169,39 @@ def test_dataparallel_world1_equals_plain_autograd(golden):
         else:
             assert p.grad is None and torch.equal(p.detach(), before[k])   # conv3_3 untouched (DenseBox.py:193-195)
     net.engine().grad_sink = None
+
+
+def test_hash_dropout_equals_injected_mask(golden):
+    """Training-mode Dropout without a mask buffer: the keep bits are a counter-based hash evaluated in the forward
+    epilogue and again in backward.  Recover the mask from the hidden activations, inject it through the buffer path
+    (which the reference-captured dropout fixture pins) and require identical outputs and gradients."""
+    g, kind, net, n, x = _setup(golden, 'train_DenseBoxLM', 'f32')
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.5
+    net.dropout_masks = None
+    outs, loss = _step(g, kind, net, n, x, 0)
+    loss.backward()
+    eng = net.engine()
+    assert eng.last_plan.drop_hash
+    hid = eng.read_activation('hid').clone()
+    g_hash = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    o_hash = [o.detach().clone() for o in outs]
+    keep = (hid != 0)
+    frac = keep.float().mean().item()
+    assert 0.49 < frac < 0.51, frac                          # p = 0.5
+    # second forward draws a different mask
+    outs2, _ = _step(g, kind, net, n, x, 0)
+    assert not torch.equal(outs2[0], o_hash[0])
+    # inject the recovered mask: buffer path
+    for p in net.parameters():
+        p.grad = None
+    net.dropout_masks = {h: keep[:, 512 * i:512 * (i + 1)].to(torch.uint8) for i, h in enumerate(['det', 'loc', 'landmark'])}
+    outs3, loss3 = _step(g, kind, net, n, x, 0)
+    assert not eng.last_plan.drop_hash
+    for a, b in zip(outs3, o_hash):
+        assert torch.equal(a.detach(), b)
+    loss3.backward()
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, g_hash[k]), k
