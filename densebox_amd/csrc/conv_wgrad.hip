@@ -228,6 +228,155 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 
 
 
+
+// ------------------------------------------------------------------------------------------------ 3x3 wide layers: one ky row per workgroup
+// The per-tap kernel above is bound by its LDS operand reads: ds_read_b64_tr_b16 runs at ~62 B/clk/CU (half the b128
+// rate, tools/probe_lds_rate.hip) and a 64x64 wave tile needs one such read per MFMA.  Here a workgroup owns a
+// 128(co) x 128(ci) tile for the THREE kx taps of one ky:
+//   * the dz fragments are read once and used for all three taps;
+//   * per x channel column a lane reads ONE run of 12 band rows (three transpose reads); the fragment of tap kx is rows
+//     kx..kx+7 of that run: kx=0 and kx=2 are register subsets, kx=1 is four v_alignbit -- 14 reads per 24 MFMAs;
+//   * global traffic per MFLOP drops 2.9x (dz tile staged once, one 34-row x band for the three taps).
+// 512 threads = 8 waves as 2(co) x 4(ci), 64x32 per wave, 3 x 8 accumulator fragments; register-staged double-buffered
+// LDS as in wgrad_kernel.  Requires dz_c % 128 == 0 and x_c % 128 == 0.  Grid: (co-tile, ci-tile, ky) x split-K.
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_row3_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit tiles");
+    constexpr int R = 64, BAND = R + 2;                                 // frame rows per K step (one global-latency period)
+    constexpr int A_BYTES = R * 256, B_BYTES = (BAND + 2) * 256;        // 128 channels x 2 B per row (+2 rows read, unused)
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // 2 x (A_BYTES + B_BYTES) = 66 KB
+    char* As = smem;
+    char* Bs = smem + 2 * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                           // wave tile 64(co) x 32(ci)
+    int t, split;
+    wg_tile_split(a.tiles_co * a.tiles_ci * 3, a.nsplit, t, split);
+    const int tile_ci = t % a.tiles_ci; t /= a.tiles_ci;
+    const int tile_co = t % a.tiles_co; t /= a.tiles_co;
+    const int ky = t;
+    const long long q0 = (long long)split * a.rows_per_split;
+    long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
+    const int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
+    const bool do_bias = (tile_ci == 0 && ky == 0 && a.bpartial != nullptr);
+
+    // loaders: thread t owns chunk t%16 of dz rows t/16 and t/16+32, of band rows t/16 and t/16+32, and (t < 32) of row t/16+64
+    const int ca = tid & 15, ra = tid >> 4;
+    const char* ap = a.dz + ((q0 + ra) * a.dz_ld + tile_co * 128) * 2LL + ca * 16;
+    const long long xrow0 = q0 + (long long)(ky + a.shift0) * a.wp + a.shift0;
+    const char* bp = a.x + ((xrow0 + ra) * a.x_ld + tile_ci * 128) * 2LL + ca * 16;
+    const long long a32 = 32LL * a.dz_ld * 2, b32 = 32LL * a.x_ld * 2;
+    const bool has2 = tid < 32;
+    u32x4 areg[2], breg[3];
+    auto gload = [&](int s) {
+        areg[0] = *(const u32x4*)(ap + s * 2 * a32);
+        areg[1] = *(const u32x4*)(ap + s * 2 * a32 + a32);
+        breg[0] = *(const u32x4*)(bp + s * 2 * b32);
+        breg[1] = *(const u32x4*)(bp + s * 2 * b32 + b32);
+        if (has2) breg[2] = *(const u32x4*)(bp + s * 2 * b32 + 2 * b32);
+    };
+    auto lstore = [&](int buf) {
+        *(u32x4*)(As + buf * A_BYTES + swz16<128>(ra, ca * 16)) = areg[0];
+        *(u32x4*)(As + buf * A_BYTES + swz16<128>(32 + ra, ca * 16)) = areg[1];
+        *(u32x4*)(Bs + buf * B_BYTES + swz16<128>(ra, ca * 16)) = breg[0];
+        *(u32x4*)(Bs + buf * B_BYTES + swz16<128>(32 + ra, ca * 16)) = breg[1];
+        if (has2) *(u32x4*)(Bs + buf * B_BYTES + swz16<128>(64 + ra, ca * 16)) = breg[2];
+    };
+    f32x4 acc[3][4][2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[k][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    auto bias_acc = [&]() {
+        const T* e0 = (const T*)&areg[0];
+        const T* e1 = (const T*)&areg[1];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += to_f32(e0[j]) + to_f32(e1[j]);
+    };
+    if (nsteps > 0) { gload(0); if (do_bias) bias_acc(); lstore(0); }
+    __syncthreads();
+    const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
+    auto trd = [&](const char* p) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
+    };
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        const char* Ab = As + buf * A_BYTES;
+        const char* Bb = Bs + buf * B_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int r0row = 32 * kk + 8 * g + rsub;
+            u32x4 af[4];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int cbyte = (wm * 64 + mi * 16) * 2 + csub;
+                const u32x2 lo = trd(Ab + swz16<128>(r0row, cbyte)), hi = trd(Ab + swz16<128>(r0row + 4, cbyte));
+                af[mi] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+            }
+            u32x4 bf[3][2];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int cbyte = (wn * 32 + ni * 16) * 2 + csub;
+                // rows r..r+11 of this channel column: dwords hold row pairs (0,1)(2,3) | (4,5)(6,7) | (8,9)(10,11)
+                const u32x2 r0 = trd(Bb + swz16<128>(r0row, cbyte));
+                const u32x2 r1 = trd(Bb + swz16<128>(r0row + 4, cbyte));
+                const u32x2 r2 = trd(Bb + swz16<128>(r0row + 8, cbyte));
+                bf[0][ni] = (u32x4){r0.x, r0.y, r1.x, r1.y};
+                bf[1][ni] = (u32x4){__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
+                                    __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)};
+                bf[2][ni] = (u32x4){r0.y, r1.x, r1.y, r2.x};
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        if constexpr (DType<T>::id == DBX_F16)
+                            acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mi]), __builtin_bit_cast(f16x8, bf[kx][ni]), acc[kx][mi][ni], 0, 0, 0);
+                        else
+                            acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[kx][ni]), acc[kx][mi][ni], 0, 0, 0);
+                    }
+        }
+        if (s + 1 < nsteps) { if (do_bias) bias_acc(); lstore(buf ^ 1); }
+        __syncthreads();
+    }
+    {
+        float* P = a.partial + (((long long)split * a.co_pad) * 9) * a.ci_pad;
+        const int co_b = tile_co * 128 + wm * 64 + (lane >> 4) * 4;
+        const int ci_b = tile_ci * 128 + wn * 32 + (lane & 15);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const float v[4] = {acc[kx][mi][ni].x, acc[kx][mi][ni].y, acc[kx][mi][ni].z, acc[kx][mi][ni].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        P[((long long)(co_b + mi * 16 + r) * 9 + ky * 3 + kx) * a.ci_pad + ci_b + ni * 16] = v[r];
+                }
+    }
+    if (do_bias) {
+        __syncthreads();
+        float* red = (float*)smem;                       // [32 rows][128]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[ra * 128 + ca * 8 + j] = bsum[j];
+        __syncthreads();
+        if (tid < 128) {
+            float sum = 0.f;
+            for (int r = 0; r < 32; ++r) sum += red[r * 128 + tid];
+            a.bpartial[(long long)split * a.co_pad + tile_co * 128 + tid] = sum;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3, all taps per workgroup
 // For layers with few channels (Cout, Cin <= 128 at 240x240 / 120x120) the per-tap tiling above is bound by refilling
 // LDS: every tap re-reads the same dz rows and a shifted copy of the same x rows (32 FLOP per byte filled).  Here one
@@ -534,7 +683,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8; long long Q; };
+struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3; long long Q; };
 
 static int wgrad_variant() {          // DBX_WGRAD_VARIANT=1: generic per-tap kernel everywhere (A/B testing)
     static int v = -1;
@@ -552,19 +701,23 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     if (p.alltaps) { p.bmc = 64; p.bnc = 64; }
     // conv1_1: 8-channel (one chunk per pixel) input, 64 couts: (tap, channel) pairs form the GEMM N dimension
     p.c8 = (p.alltaps && x->c * dbx_esize(dtype) == 16 && x->ld == x->c && dz->c == 64 && wgrad_variant() != 4) ? 1 : 0;
+    // wide 3x3 layers: one ky row (three kx taps) per workgroup, 128x128 tiles (DBX_WGRAD_VARIANT=6: per-tap kernel)
+    p.row3 = (!p.alltaps && dtype != DBX_F32 && kh == 3 && kw == 3 && dz->c % 128 == 0 && x->c % 128 == 0 && wgrad_variant() != 6) ? 1 : 0;
     p.co_pad = (dz->c + p.bmc - 1) / p.bmc * p.bmc;
     p.ci_pad = p.c8 ? 8 : (x->c + p.bnc - 1) / p.bnc * p.bnc;
     p.tiles_co = p.co_pad / p.bmc; p.tiles_ci = p.c8 ? 1 : p.ci_pad / p.bnc;
     p.taps = kh * kw;
     p.Q = (long long)dz->n * (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad);
-    const long long tiles = (long long)p.tiles_co * p.tiles_ci * (p.alltaps ? 1 : p.taps);
+    const long long tiles = (long long)p.tiles_co * p.tiles_ci * (p.alltaps ? 1 : (p.row3 ? 3 : p.taps));
     const long long steps = (p.Q + 31) / 32;
     // aim for ~4 workgroups per CU (2 resident per CU); the c8 kernel streams dz once: 2 workgroups per CU suffice
-    long long splits = ((p.c8 ? 512 : 1024) + tiles - 1) / tiles;
+    // row3: one 512-thread workgroup per CU, three full rounds of 256 workgroups
+    long long splits = ((p.row3 ? 768 : p.c8 ? 512 : 1024) + tiles - 1) / tiles;
     const long long max_by_steps = steps / 16 > 0 ? steps / 16 : 1;   // at least 16 K-steps (512 rows) per split
     if (splits > max_by_steps) splits = max_by_steps;
     if (splits > (p.c8 ? 512 : 256)) splits = p.c8 ? 512 : 256;
     if (splits < 1) splits = 1;
+    { static int ov = -1; if (ov < 0) { const char* e = getenv("DBX_WGRAD_SPLITS"); ov = e ? atoi(e) : 0; } if (ov > 0 && !p.alltaps) splits = ov; }
     if (splits >= 8) splits = (splits + 7) / 8 * 8;           // XCD-aware workgroup mapping wants a multiple of 8
     long long sps = (steps + splits - 1) / splits;
     sps = (sps + 1) / 2 * 2;                                   // whole 64-row K steps for the R=64 kernel
@@ -604,6 +757,16 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     } else if (p.alltaps) {
         if constexpr (sizeof(T) == 2)
             hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), 0, s, a);
+    } else if (p.row3) {
+        if constexpr (sizeof(T) == 2) {
+            constexpr int smem = 2 * (64 * 256 + 68 * 256);
+            static bool attr_set = false;
+            if (!attr_set) {
+                DBX_HIP(hipFuncSetAttribute((const void*)wgrad_row3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((wgrad_row3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * 3 * p.splits), dim3(512), smem, s, a);
+        }
     } else {
         const dim3 grid(p.tiles_co * p.tiles_ci * p.taps * p.splits);
         if (p.bmc == 128) hipLaunchKernelGGL((wgrad_kernel<T, 128, 128>), grid, dim3(256), 0, s, a);

@@ -514,6 +514,8 @@ class Engine:
             tn = ('f16', 'bf16', 'f32')[dt]
             if dt != _lib.F32 and kh == 3 and kw == 3 and dz.c <= 128 and x.c <= 128:
                 name = ('wgrad3x3_c8_kernel<%s>' if (x.c * _lib.ESIZE[dt] == 16 and dz.c == 64) else 'wgrad3x3_kernel<%s>') % tn
+            elif dt != _lib.F32 and kh == 3 and kw == 3 and dz.c % 128 == 0 and x.c % 128 == 0:
+                name = 'wgrad_row3_kernel<%s>' % tn
             else:
                 name = 'wgrad_kernel<%s,%s>' % (tn, '128,128' if big else '64,64')
             prof.append({'kernel': name, 'flops': 2.0 * dz.n * dz.h * dz.w * kh * kw * ci * co, 'start': ev0, 'end': ev1})
