@@ -229,6 +229,149 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 
 
 
+// ------------------------------------------------------------------------------------------------ wide 1x1 layers: 256 x 256 tiles
+// The stage-1 head GEMM (768 -> 2048 over every pixel) has no taps to share, so the LDS-read relief comes from the wave
+// tile alone: 256(co) x 256(ci) per workgroup, 8 waves as 4(co) x 2(ci) with 64 x 128 per wave -- 0.75 transpose reads
+// per MFMA instead of 1.0 and half the staged bytes per FLOP of the 128 x 128 tile.  64-row K steps (64 MFMAs per wave
+// per barrier) cover the ~0.85 us global-load latency with the single register-staged prefetch.  128 KB of LDS, one
+// workgroup per CU.  Requires dz_c % 256 == 0 and x_c % 256 == 0.  Grid: (co-tile, ci-tile, tap) x split-K.
+__device__ __forceinline__ int swz16w(int r, int b) {                   // 256 channels (512 B) per row, same XOR mask as swz16<128>
+    return r * 512 + (b ^ (((r & 3) << 5) | (((r >> 3) & 1) << 7)));
+}
+
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_wide_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit tiles");
+    constexpr int R = 64;
+    constexpr int T_BYTES = R * 512;                                    // one operand tile: 64 rows x 256 channels
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // 2 buffers x (A, B) = 128 KB
+    char* As = smem;
+    char* Bs = smem + 2 * T_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                           // wave tile 64(co) x 128(ci)
+    int t, split;
+    wg_tile_split(a.tiles_co * a.tiles_ci * a.taps, a.nsplit, t, split);
+    const int tile_ci = t % a.tiles_ci; t /= a.tiles_ci;
+    const int tile_co = t % a.tiles_co; t /= a.tiles_co;
+    const int tap = t, ky = tap / a.kw, kx = tap - ky * a.kw;
+    const long long q0 = (long long)split * a.rows_per_split;
+    long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
+    const int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
+    const bool do_bias = (tile_ci == 0 && tap == 0 && a.bpartial != nullptr);
+
+    // loaders: thread t owns chunk t%32 of rows t/32 + 16 i (i = 0..3) of both tiles
+    const int ca = tid & 31, ra = tid >> 5;
+    const char* ap = a.dz + ((q0 + ra) * a.dz_ld + tile_co * 256) * 2LL + ca * 16;
+    const long long xrow0 = q0 + (long long)(ky + a.shift0) * a.wp + kx + a.shift0;
+    const char* bp = a.x + ((xrow0 + ra) * a.x_ld + tile_ci * 256) * 2LL + ca * 16;
+    const long long a16 = 16LL * a.dz_ld * 2, b16 = 16LL * a.x_ld * 2;
+    u32x4 areg[4], breg[4];
+    auto gload = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            areg[i] = *(const u32x4*)(ap + (s * 4 + i) * a16);
+            breg[i] = *(const u32x4*)(bp + (s * 4 + i) * b16);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(u32x4*)(As + buf * T_BYTES + swz16w(ra + 16 * i, ca * 16)) = areg[i];
+            *(u32x4*)(Bs + buf * T_BYTES + swz16w(ra + 16 * i, ca * 16)) = breg[i];
+        }
+    };
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    auto bias_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const T* e = (const T*)&areg[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[j] += to_f32(e[j]);
+        }
+    };
+    if (nsteps > 0) { gload(0); if (do_bias) bias_acc(); lstore(0); }
+    __syncthreads();
+    const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
+    auto trd = [&](const char* p) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
+    };
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) gload(s + 1);
+        const char* Ab = As + buf * T_BYTES;
+        const char* Bb = Bs + buf * T_BYTES;
+        // software pipeline over the 16 (kk, ni) groups of four MFMAs: the B fragment of the next group and one of the
+        // next kk's A fragments are in flight while the current group computes; sched_group_barrier pins the interleave.
+        auto rdA = [&](int kk, int mi) {
+            const int r0 = 32 * kk + 8 * g + rsub, cbyte = (wm * 64 + mi * 16) * 2 + csub;
+            const u32x2 lo = trd(Ab + swz16w(r0, cbyte)), hi = trd(Ab + swz16w(r0 + 4, cbyte));
+            return (u32x4){lo.x, lo.y, hi.x, hi.y};
+        };
+        auto rdB = [&](int kk, int ni) {
+            const int r0 = 32 * kk + 8 * g + rsub, cbyte = (wn * 128 + ni * 16) * 2 + csub;
+            const u32x2 lo = trd(Bb + swz16w(r0, cbyte)), hi = trd(Bb + swz16w(r0 + 4, cbyte));
+            return (u32x4){lo.x, lo.y, hi.x, hi.y};
+        };
+        u32x4 af[2][4], bf[2];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[0][mi] = rdA(0, mi);
+        bf[0] = rdB(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+        for (int grp = 0; grp < 16; ++grp) {
+            const int kk = grp >> 3, ni = grp & 7;
+            if (grp < 15) bf[(grp + 1) & 1] = rdB((grp + 1) >> 3, (grp + 1) & 7);
+            if (grp < 4) af[1][grp] = rdA(1, grp);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                if constexpr (DType<T>::id == DBX_F16)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[kk][mi]), __builtin_bit_cast(f16x8, bf[grp & 1]), acc[mi][ni], 0, 0, 0);
+                else
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kk][mi]), __builtin_bit_cast(bf16x8, bf[grp & 1]), acc[mi][ni], 0, 0, 0);
+            }
+            if (grp < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            else if (grp < 15) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        if (s + 1 < nsteps) { if (do_bias) bias_acc(); lstore(buf ^ 1); }
+        __syncthreads();
+    }
+    {
+        float* P = a.partial + (((long long)split * a.co_pad) * a.taps) * a.ci_pad;
+        const int co_b = tile_co * 256 + wm * 64 + (lane >> 4) * 4;
+        const int ci_b = tile_ci * 256 + wn * 128 + (lane & 15);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                const float v[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    P[((long long)(co_b + mi * 16 + r) * a.taps + tap) * a.ci_pad + ci_b + ni * 16] = v[r];
+            }
+    }
+    if (do_bias) {
+        __syncthreads();
+        float* red = (float*)smem;                       // [16 row groups][256]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[ra * 256 + ca * 8 + j] = bsum[j];
+        __syncthreads();
+        if (tid < 256) {
+            float sum = 0.f;
+            for (int r = 0; r < 16; ++r) sum += red[r * 256 + tid];
+            a.bpartial[(long long)split * a.co_pad + tile_co * 256 + tid] = sum;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3 wide layers: one ky row per workgroup
 // The per-tap kernel above is bound by its LDS operand reads: ds_read_b64_tr_b16 runs at ~62 B/clk/CU (half the b128
 // rate, tools/probe_lds_rate.hip) and a 64x64 wave tile needs one such read per MFMA.  Here a workgroup owns a
@@ -309,40 +452,51 @@ __global__ __launch_bounds__(512) void wgrad_row3_kernel(const WgradArgs a) {
         if (s + 1 < nsteps) gload(s + 1);
         const char* Ab = As + buf * A_BYTES;
         const char* Bb = Bs + buf * B_BYTES;
+        // software pipeline over the four (kk, ni) units of 3 x 4 MFMAs: the 12-row run of the next unit and half of the
+        // next kk's dz fragments are in flight while the current unit computes; sched_group_barrier pins the interleave.
+        auto rdA = [&](int kk, int mi) {
+            const int r0 = 32 * kk + 8 * g + rsub, cbyte = (wm * 64 + mi * 16) * 2 + csub;
+            const u32x2 lo = trd(Ab + swz16<128>(r0, cbyte)), hi = trd(Ab + swz16<128>(r0 + 4, cbyte));
+            return (u32x4){lo.x, lo.y, hi.x, hi.y};
+        };
+        struct Run { u32x2 r0, r1, r2; };      // rows r..r+11 of one channel column: row pairs (0,1)(2,3) | (4,5)(6,7) | (8,9)(10,11)
+        auto rdRun = [&](int u) {
+            const int r0 = 32 * (u >> 1) + 8 * g + rsub, cbyte = (wn * 32 + (u & 1) * 16) * 2 + csub;
+            Run r;
+            r.r0 = trd(Bb + swz16<128>(r0, cbyte)); r.r1 = trd(Bb + swz16<128>(r0 + 4, cbyte)); r.r2 = trd(Bb + swz16<128>(r0 + 8, cbyte));
+            return r;
+        };
+        u32x4 af[2][4];
+        Run run[2];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int r0row = 32 * kk + 8 * g + rsub;
-            u32x4 af[4];
+        for (int mi = 0; mi < 4; ++mi) af[0][mi] = rdA(0, mi);
+        run[0] = rdRun(0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 11, 0);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int cbyte = (wm * 64 + mi * 16) * 2 + csub;
-                const u32x2 lo = trd(Ab + swz16<128>(r0row, cbyte)), hi = trd(Ab + swz16<128>(r0row + 4, cbyte));
-                af[mi] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+        for (int u = 0; u < 4; ++u) {
+            const int kk = u >> 1, ni = u & 1;
+            const Run c = run[u & 1];
+            if (u < 3) run[(u + 1) & 1] = rdRun(u + 1);
+            if (u < 2) { af[1][2 * u] = rdA(1, 2 * u); af[1][2 * u + 1] = rdA(1, 2 * u + 1); }
+            u32x4 bf[3];
+            bf[0] = (u32x4){c.r0.x, c.r0.y, c.r1.x, c.r1.y};
+            bf[1] = (u32x4){__builtin_amdgcn_alignbit(c.r0.y, c.r0.x, 16), __builtin_amdgcn_alignbit(c.r1.x, c.r0.y, 16),
+                            __builtin_amdgcn_alignbit(c.r1.y, c.r1.x, 16), __builtin_amdgcn_alignbit(c.r2.x, c.r1.y, 16)};
+            bf[2] = (u32x4){c.r0.y, c.r1.x, c.r1.y, c.r2.x};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    if constexpr (DType<T>::id == DBX_F16)
+                        acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[kk][mi]), __builtin_bit_cast(f16x8, bf[kx]), acc[kx][mi][ni], 0, 0, 0);
+                    else
+                        acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kk][mi]), __builtin_bit_cast(bf16x8, bf[kx]), acc[kx][mi][ni], 0, 0, 0);
+                }
+                if (u < 2 && kx == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // 3 run reads + 4 dz reads
+                else if (u < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (u < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);              // 3 run reads
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
-            u32x4 bf[3][2];
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int cbyte = (wn * 32 + ni * 16) * 2 + csub;
-                // rows r..r+11 of this channel column: dwords hold row pairs (0,1)(2,3) | (4,5)(6,7) | (8,9)(10,11)
-                const u32x2 r0 = trd(Bb + swz16<128>(r0row, cbyte));
-                const u32x2 r1 = trd(Bb + swz16<128>(r0row + 4, cbyte));
-                const u32x2 r2 = trd(Bb + swz16<128>(r0row + 8, cbyte));
-                bf[0][ni] = (u32x4){r0.x, r0.y, r1.x, r1.y};
-                bf[1][ni] = (u32x4){__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
-                                    __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)};
-                bf[2][ni] = (u32x4){r0.y, r1.x, r1.y, r2.x};
-            }
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        if constexpr (DType<T>::id == DBX_F16)
-                            acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mi]), __builtin_bit_cast(f16x8, bf[kx][ni]), acc[kx][mi][ni], 0, 0, 0);
-                        else
-                            acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[kx][ni]), acc[kx][mi][ni], 0, 0, 0);
-                    }
         }
         if (s + 1 < nsteps) { if (do_bias) bias_acc(); lstore(buf ^ 1); }
         __syncthreads();
@@ -683,7 +837,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3; long long Q; };
+struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3, wide; long long Q; };
 
 static int wgrad_variant() {          // DBX_WGRAD_VARIANT=1: generic per-tap kernel everywhere (A/B testing)
     static int v = -1;
@@ -703,6 +857,9 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     p.c8 = (p.alltaps && x->c * dbx_esize(dtype) == 16 && x->ld == x->c && dz->c == 64 && wgrad_variant() != 4) ? 1 : 0;
     // wide 3x3 layers: one ky row (three kx taps) per workgroup, 128x128 tiles (DBX_WGRAD_VARIANT=6: per-tap kernel)
     p.row3 = (!p.alltaps && dtype != DBX_F32 && kh == 3 && kw == 3 && dz->c % 128 == 0 && x->c % 128 == 0 && wgrad_variant() != 6) ? 1 : 0;
+    // wide 1x1 layers: 256x256 tiles (DBX_WGRAD_VARIANT=7: 128x128 per-tap kernel)
+    p.wide = (dtype != DBX_F32 && kh == 1 && kw == 1 && dz->c % 256 == 0 && x->c % 256 == 0 && wgrad_variant() != 7) ? 1 : 0;
+    if (p.wide) { p.bmc = 256; p.bnc = 256; }
     p.co_pad = (dz->c + p.bmc - 1) / p.bmc * p.bmc;
     p.ci_pad = p.c8 ? 8 : (x->c + p.bnc - 1) / p.bnc * p.bnc;
     p.tiles_co = p.co_pad / p.bmc; p.tiles_ci = p.c8 ? 1 : p.ci_pad / p.bnc;
@@ -712,7 +869,7 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     const long long steps = (p.Q + 31) / 32;
     // aim for ~4 workgroups per CU (2 resident per CU); the c8 kernel streams dz once: 2 workgroups per CU suffice
     // row3: one 512-thread workgroup per CU, three full rounds of 256 workgroups
-    long long splits = ((p.row3 ? 768 : p.c8 ? 512 : 1024) + tiles - 1) / tiles;
+    long long splits = ((p.row3 || p.wide ? 768 : p.c8 ? 512 : 1024) + tiles - 1) / tiles;
     const long long max_by_steps = steps / 16 > 0 ? steps / 16 : 1;   // at least 16 K-steps (512 rows) per split
     if (splits > max_by_steps) splits = max_by_steps;
     if (splits > (p.c8 ? 512 : 256)) splits = p.c8 ? 512 : 256;
@@ -766,6 +923,16 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
                 attr_set = true;
             }
             hipLaunchKernelGGL((wgrad_row3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * 3 * p.splits), dim3(512), smem, s, a);
+        }
+    } else if (p.wide) {
+        if constexpr (sizeof(T) == 2) {
+            constexpr int smem = 4 * 64 * 512;
+            static bool attr_set = false;
+            if (!attr_set) {
+                DBX_HIP(hipFuncSetAttribute((const void*)wgrad_wide_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((wgrad_wide_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.taps * p.splits), dim3(512), smem, s, a);
         }
     } else {
         const dim3 grid(p.tiles_co * p.tiles_ci * p.taps * p.splits);
