@@ -71,12 +71,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI
     const int cb = n0 + wn_off + (lane >> 4) * 4;
     const int mb = m0 + wm_off + (lane & 15);
     const int epi = a.epi;
+    // pixel coordinates: divided out once, then advanced 16 pixels per fragment row
+    int n = mb / a.HoWo, r = mb - n * a.HoWo;
+    int oy = r / a.Wo, ox = r - oy * a.Wo;
+    const int Ho = a.HoWo / a.Wo;
+    const bool stepwise = a.Wo >= 16;                       // one row wrap at most per 16-pixel advance
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = mb + mi * 16;
+        if (mi > 0) {
+            if (stepwise) {
+                ox += 16; r += 16;
+                if (ox >= a.Wo) { ox -= a.Wo; if (++oy == Ho) { oy = 0; ++n; r -= a.HoWo; } }
+            } else {
+                n = m / a.HoWo; r = m - n * a.HoWo;
+                oy = r / a.Wo; ox = r - oy * a.Wo;
+            }
+        }
         if (m >= a.M) continue;
-        const int n = m / a.HoWo, r = m - n * a.HoWo;
-        const int oy = r / a.Wo, ox = r - oy * a.Wo;
         const size_t ypix = ((size_t)(n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
         const size_t gpix = ((size_t)(n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld;
 #pragma unroll
@@ -516,48 +528,74 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) Mma<T>::run(w[ni], x[mi], acc[ni][mi]);
         };
+        // sched_group_barrier pins the interleave (the scheduler otherwise bunches both taps' reads in front of one
+        // lgkmcnt(0)): RPS reads of the next tap after each group of four MFMAs of the current one.
+        constexpr int RD = MI + NI, SG = MI * NI / 4, RPS = (RD + SG - 1) / SG, NSGR = (RD + RPS - 1) / RPS;
         rd(0, wf[0], xf[0]);
-        rd(1, wf[1], xf[1]);
-        mm(wf[0], xf[0]);
-        rd(2, wf[0], xf[0]);
-        mm(wf[1], xf[1]);
-        mm(wf[0], xf[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (t < 2) rd(t + 1, wf[(t + 1) & 1], xf[(t + 1) & 1]);
+            mm(wf[t & 1], xf[t & 1]);
+#pragma unroll
+            for (int sg = 0; sg < SG; ++sg) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                if (t < 2 && sg < NSGR) __builtin_amdgcn_sched_group_barrier(0x100, RPS, 0);
+            }
+        }
         stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
 
-    // ---- epilogue over frame pixels: only interior pixels are stored (the frame of y stays zero)
+    // ---- epilogue over frame pixels: only interior pixels are stored (the frame of y stays zero).  The frame coordinates
+    // are divided out once and then advanced 16 pixels per fragment row; bias is fetched once per column fragment.
     const int cb = n0 + wn * WTN + (lane >> 4) * 4;
     const int epi = a.epi;
-    const int fpix = a.x_hp * a.x_wp;
+    const int fpix = a.x_hp * a.x_wp, nimg = a.M / a.HoWo;
+    f32x4 bias[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+        bias[ni] = ((epi & DBX_EPI_BIAS) && cb + ni * 16 < a.cout_valid) ? *(const f32x4*)(a.bias + cb + ni * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    int n, fy, fx;
+    {
+        const long long q = q0 + wm * WTM + (lane & 15);
+        n = (int)(q / fpix);
+        const int rem = (int)(q - (long long)n * fpix);
+        fy = rem / a.x_wp; fx = rem - fy * a.x_wp;
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        const long long q = q0 + wm * WTM + mi * 16 + (lane & 15);
-        const int n = (int)(q / fpix), rem = (int)(q - (long long)n * fpix);
-        const int fy = rem / a.x_wp, fx = rem - fy * a.x_wp;
-        if (n >= a.M / a.HoWo || fy < 1 || fy > a.x_hp - 2 || fx < 1 || fx > a.x_wp - 2) continue;
-        const int oy = fy - 1, ox = fx - 1;
-        const size_t ypix = ((size_t)(n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
-        const size_t gpix = ((size_t)(n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld;
+        if (n < nimg && fy >= 1 && fy <= a.x_hp - 2 && fx >= 1 && fx <= a.x_wp - 2) {
+            const int oy = fy - 1, ox = fx - 1;
+            T* yrow = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld + cb;
+            const T* grow = (const T*)a.gate + (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld + cb;
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int c = cb + ni * 16;
-            if (c >= a.cout_valid) continue;
-            f32x4 v = acc[ni][mi];
-            if (epi & DBX_EPI_BIAS) v += *(const f32x4*)(a.bias + c);
-            if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (epi & DBX_EPI_GATE) {
-                const T* gt = (const T*)a.gate + gpix + c;
-                v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
-                v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
+            for (int ni = 0; ni < NI; ++ni) {
+                if (cb + ni * 16 >= a.cout_valid) continue;
+                f32x4 v = acc[ni][mi] + bias[ni];
+                if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (epi & DBX_EPI_GATE) {
+                    const T* gt = grow + ni * 16;
+                    v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
+                    v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
+                }
+                T* o = yrow + ni * 16;
+                if (epi & DBX_EPI_ACCUM) { v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]); }
+                if constexpr (sizeof(T) == 2) {
+                    T pk[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+                    *(u32x2*)o = *(const u32x2*)pk;
+                } else {
+                    *(f32x4*)o = v;
+                }
             }
-            T* o = (T*)a.y + ypix + c;
-            if (epi & DBX_EPI_ACCUM) { v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]); }
-            if constexpr (sizeof(T) == 2) {
-                T pk[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
-                *(u32x2*)o = *(const u32x2*)pk;
-            } else {
-                *(f32x4*)o = v;
-            }
+        }
+        if (a.x_wp >= 16) {                                  // one row wrap at most per 16-pixel advance
+            fx += 16;
+            if (fx >= a.x_wp) { fx -= a.x_wp; if (++fy == a.x_hp) { fy = 0; ++n; } }
+        } else {
+            const long long q = q0 + wm * WTM + (mi + 1) * 16 + (lane & 15);
+            n = (int)(q / fpix);
+            const int rem = (int)(q - (long long)n * fpix);
+            fy = rem / a.x_wp; fx = rem - fy * a.x_wp;
         }
     }
 }
