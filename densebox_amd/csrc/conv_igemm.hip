@@ -41,6 +41,15 @@ struct ConvArgs {
     unsigned drop_seed;
 };
 
+// XOR mask (in 16-byte chunks) of a tile row, applied on the LDS-DMA source side and on the fragment reads.
+// tools/probe_lds_swizzle.hip finds maps with a higher isolated ds_read_b128 rate ((r0^r1^r2, r1^r2^r3) for 64-byte rows,
+// (r2, r3, r1) for 128-byte rows), but in the kernels they measured 2 % slower end to end (the per-row source permutation
+// costs more on the global side than the reads gain), so the block maps stay.
+template <int BKB> __device__ __forceinline__ int dma_swz(int row) {
+    if (BKB == 128) return (row >> 1) & 7;                                   // 2 rows per 256-B bank row
+    else return (0x1320 >> (((row >> 2) & 3) * 4)) & 3;                      // 4 rows per bank row: F = {0,2,3,1}
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<_Float16> {
     static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x4& c) {
@@ -65,12 +74,20 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int MI, int NI>
+// HOIST: fetch the bias fragments once up front (a win for the one-tile-per-workgroup v1 kernel; in the persistent DMA
+// kernel the early loads make the compiler drain vmcnt in front of the next tile's LDS-DMA issue, so it stays per-fragment).
+template <typename T, int MI, int NI, bool HOIST = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI][MI], int m0, int n0, int wm_off, int wn_off, int lane) {
     // ---- epilogue: lane holds couts cb + ni*16 + (l>>4)*4 + {0..3} of pixel mb + mi*16 + (l&15)
     const int cb = n0 + wn_off + (lane >> 4) * 4;
     const int mb = m0 + wm_off + (lane & 15);
     const int epi = a.epi;
+    f32x4 hbias[HOIST ? NI : 1];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+            hbias[ni] = ((epi & DBX_EPI_BIAS) && cb + ni * 16 < a.cout_valid) ? *(const f32x4*)(a.bias + cb + ni * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     // pixel coordinates: divided out once, then advanced 16 pixels per fragment row
     int n = mb / a.HoWo, r = mb - n * a.HoWo;
     int oy = r / a.Wo, ox = r - oy * a.Wo;
@@ -96,7 +113,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI
             const int c = cb + ni * 16;
             if (c >= a.cout_valid) continue;
             f32x4 v = acc[ni][mi];
-            if (epi & DBX_EPI_BIAS) {
+            if constexpr (HOIST) {
+                v += hbias[ni];
+            } else if (epi & DBX_EPI_BIAS) {
                 const f32x4 b = *(const f32x4*)(a.bias + c);
                 v += b;
             }
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     for (int i = 0; i < B_LD; ++i) brow[i] = a.w + (size_t)(n0 + lrow + 32 * i) * a.ktot_bytes + lchunk * 16;
 
     const int pix_bytes = a.x_ld * ES;
-    const int sw_w = ((lrow >> 1) & 7);   // (row>>1)&7 is the same for rows lrow+32*i
+    const int sw_w = dma_swz<128>(lrow);  // uses row bits 1..3: the same for rows lrow+32*i
     const int lds_w = lrow * 128 + ((lchunk ^ sw_w) << 4);
 
     u32x4 areg[A_LD], breg[B_LD];
@@ -222,7 +241,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     // fragment read offsets: row (l&15) of a 16-row fragment, logical chunk kk*4 + (l>>4)
     const int fr = lane & 15;
-    const int c0sw = ((lane >> 4) ^ ((lane >> 1) & 7)) << 4;   // kk = 0; kk = 1 flips bit 6 (chunk ^ 4)
+    const int c0sw = ((lane >> 4) ^ dma_swz<128>(fr)) << 4;    // kk = 0; kk = 1 flips bit 6 (chunk ^ 4)
     const int rd_a = (wm * WTM + fr) * 128;
     const int rd_b = (wn * WTN + fr) * 128;
 
@@ -251,7 +270,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         __syncthreads();
     }
 
-    conv_epilogue<T, MI, NI>(a, acc, m0, n0, wm * WTM, wn * WTN, lane);
+    conv_epilogue<T, MI, NI, true>(a, acc, m0, n0, wm * WTM, wn * WTN, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ v2: LDS-DMA ring
@@ -266,10 +285,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 // Template: BM x BN tile, BKB bytes of K per row per step (128 or 64), STAGES-deep ring, WM x WN waves (8 total).
 //   <256,128,128,3,4,2> / <256,64,128,3,8,1>: 64x64 (32x64) per wave, loads 2 steps ahead
 //   <256,256, 64,4,2,4>                     : 128x64 per wave, loads 3 steps ahead; 1.5x fewer staged bytes per FLOP
-template <int BKB> __device__ __forceinline__ int dma_swz(int row) {        // XOR mask (in 16-byte chunks) of a tile row
-    if (BKB == 128) return (row >> 1) & 7;                                   // 2 rows per 256-B bank row
-    else return (0x1320 >> (((row >> 2) & 3) * 4)) & 3;                      // 4 rows per bank row: F = {0,2,3,1}
-}
 
 template <typename T, int BM, int BN, int BKB, int STAGES, int WM, int WN>
 __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
@@ -707,7 +722,7 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     DBX_REQUIRE(a.M > 0 && (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < (int64_t)1 << 40, "conv: empty or oversized input");
 
     // 3x3 / pad 1 on congruent frames (x.pad == 1), 16-bit, plain NHWC epilogue: the band kernel over the linearised frame
-    if (!smallc && sizeof(T) == 2 && conv_variant() == 0 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 &&
+    if (!smallc && sizeof(T) == 2 && (conv_variant() == 0 || conv_variant() == 4) && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 &&
         !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK | DBX_EPI_DROPHASH)) && (d->cin_pad * ES) % 64 == 0 && y->c % 64 == 0) {
         const long long Q = (long long)x->n * a.x_hp * a.x_wp;
         const int tiles256 = (int)((Q + 255) / 256), tiles512 = (int)((Q + 511) / 512);
