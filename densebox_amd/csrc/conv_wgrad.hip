@@ -541,11 +541,13 @@ __global__ __launch_bounds__(512) void wgrad_row3_kernel(const WgradArgs a) {
 template <typename T>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
     static_assert(sizeof(T) == 2, "16-bit tiles");
-    constexpr int R = 32, BAND = R + 2;
-    constexpr int A_BYTES = R * 128, B_BYTES = 3 * BAND * 128;       // 64 channels x 2 B per row
-    constexpr int B_CHUNKS = 3 * BAND * 8;                            // 816 16-byte chunks
-    constexpr int LD_B = (B_CHUNKS + 255) / 256;                      // 4 per thread (last one partial)
-    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+    // Per ky band the three kx fragments of a channel column come from ONE 12-row register run (see wgrad_row3_kernel):
+    // 22 transpose reads per 36 MFMAs instead of 40.  (64-row K steps do not fit: 144 accumulator registers + staging.)
+    constexpr int R = 32, BAND = R + 2, BROWS = BAND + 2;              // +2 rows read by the runs, never used
+    constexpr int A_BYTES = R * 128, B_BYTES = 3 * BROWS * 128;        // 64 channels x 2 B per row
+    constexpr int A_CHUNKS = R * 8, B_CHUNKS = 3 * BAND * 8;           // 256 and 816 16-byte chunks
+    constexpr int LD_A = A_CHUNKS / 256, LD_B = (B_CHUNKS + 255) / 256;   // 1 and 4 (last one partial) per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // 2 x (A_BYTES + B_BYTES) = 35 KB
     char* As = smem;
     char* Bs = smem + 2 * A_BYTES;
 
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
     const int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
     const bool do_bias = (tile_ci == 0 && a.bpartial != nullptr);
 
-    // ---- loaders: dz 32 rows x 8 chunks (1 per thread); x 3 bands x 34 rows x 8 chunks
+    // ---- loaders: dz R rows x 8 chunks; x 3 bands x (R+2) rows x 8 chunks
     const int ca = tid & 7, ra = tid >> 3;
     const bool a_ok = (tile_co * 128 + ca * 16) < a.dz_c * 2;
     const char* ap = a.dz + ((q0 + ra) * a.dz_ld + tile_co * 64) * 2LL + ca * 16;
@@ -571,22 +573,24 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < LD_B; ++i) {
         const int c = tid + 256 * i;                                  // chunk id
-        const int row = c >> 3, cb = c & 7;                           // LDS row (band*34 + j), chunk in row
+        const int row = c >> 3, cb = c & 7;                           // (band, j) = (row / BAND, row % BAND), chunk in row
         const int band = row / BAND, j = row - band * BAND;
         b_ok[i] = c < B_CHUNKS && (tile_ci * 128 + cb * 16) < a.x_c * 2;
         const long long grow = q0 + (long long)(band + a.shift0) * a.wp + a.shift0 + j;
         bp[i] = a.x + (grow * a.x_ld + tile_ci * 64) * 2LL + cb * 16;
-        b_lds[i] = c < B_CHUNKS ? swz16<64>(row, cb * 16) : 0;
+        b_lds[i] = c < B_CHUNKS ? swz16<64>(band * BROWS + j, cb * 16) : 0;
     }
-    u32x4 areg, breg[LD_B];
+    u32x4 areg[LD_A], breg[LD_B];
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     auto gload = [&](int s) {
-        areg = a_ok ? *(const u32x4*)(ap + (long long)s * R * a_row) : zero4;
+#pragma unroll
+        for (int i = 0; i < LD_A; ++i) areg[i] = a_ok ? *(const u32x4*)(ap + ((long long)s * R + 32 * i) * a_row) : zero4;
 #pragma unroll
         for (int i = 0; i < LD_B; ++i) breg[i] = b_ok[i] ? *(const u32x4*)(bp[i] + (long long)s * R * b_row) : zero4;
     };
     auto lstore = [&](int buf) {
-        *(u32x4*)(As + buf * A_BYTES + swz16<64>(ra, ca * 16)) = areg;
+#pragma unroll
+        for (int i = 0; i < LD_A; ++i) *(u32x4*)(As + buf * A_BYTES + swz16<64>(ra + 32 * i, ca * 16)) = areg[i];
 #pragma unroll
         for (int i = 0; i < LD_B; ++i)
             if (tid + 256 * i < B_CHUNKS) *(u32x4*)(Bs + buf * B_BYTES + b_lds[i]) = breg[i];
@@ -603,50 +607,68 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
     auto bias_acc = [&]() {
-        const T* e = (const T*)&areg;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bsum[j] += to_f32(e[j]);
+        for (int i = 0; i < LD_A; ++i) {
+            const T* e = (const T*)&areg[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[j] += to_f32(e[j]);
+        }
     };
 
     if (nsteps > 0) { gload(0); if (do_bias) bias_acc(); lstore(0); }
     __syncthreads();
     const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
+    auto trd = [&](const char* p) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
+    };
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         if (s + 1 < nsteps) gload(s + 1);
         const char* Ab = As + buf * A_BYTES;
         const char* Bb = Bs + buf * B_BYTES;
+        // software pipeline over the six (ky, ni) units of 3 x 2 MFMAs: the 12-row run of the next unit is in flight while
+        // the current unit computes; sched_group_barrier pins the interleave.
+        const int r0 = 8 * g + rsub;
         u32x4 af[2];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int cbyte = (wm * 32 + mi * 16) * 2 + csub;
-            const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Ab + swz16<64>(8 * g + rsub, cbyte)));
-            const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Ab + swz16<64>(8 * g + 4 + rsub, cbyte)));
-            const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-            af[mi] = (u32x4){l2.x, l2.y, h2.x, h2.y};
+            const u32x2 lo = trd(Ab + swz16<64>(r0, cbyte)), hi = trd(Ab + swz16<64>(r0 + 4, cbyte));
+            af[mi] = (u32x4){lo.x, lo.y, hi.x, hi.y};
         }
+        struct Run { u32x2 c0, c1, c2; };      // rows rb..rb+11 of one channel column: row pairs (0,1)(2,3) | (4,5)(6,7) | (8,9)(10,11)
+        auto rdRun = [&](int u) {
+            const int cbyte = (wn * 32 + (u & 1) * 16) * 2 + csub, rb = (u >> 1) * BROWS + r0;
+            Run r;
+            r.c0 = trd(Bb + swz16<64>(rb, cbyte)); r.c1 = trd(Bb + swz16<64>(rb + 4, cbyte)); r.c2 = trd(Bb + swz16<64>(rb + 8, cbyte));
+            return r;
+        };
+        Run run[2];
+        run[0] = rdRun(0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ky = t / 3, kx = t - ky * 3;
-            const int rbase = ky * BAND + kx;                          // band row of q-row 0 for this tap
-            u32x4 bf[2];
+        for (int u = 0; u < 6; ++u) {
+            const int ky = u >> 1, ni = u & 1;
+            const Run c = run[u & 1];
+            if (u < 5) run[(u + 1) & 1] = rdRun(u + 1);
+            u32x4 bf[3];
+            bf[0] = (u32x4){c.c0.x, c.c0.y, c.c1.x, c.c1.y};
+            bf[1] = (u32x4){__builtin_amdgcn_alignbit(c.c0.y, c.c0.x, 16), __builtin_amdgcn_alignbit(c.c1.x, c.c0.y, 16),
+                            __builtin_amdgcn_alignbit(c.c1.y, c.c1.x, 16), __builtin_amdgcn_alignbit(c.c2.x, c.c1.y, 16)};
+            bf[2] = (u32x4){c.c0.y, c.c1.x, c.c1.y, c.c2.x};
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int cbyte = (wn * 32 + ni * 16) * 2 + csub;
-                const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Bb + swz16<64>(rbase + 8 * g + rsub, cbyte)));
-                const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(Bb + swz16<64>(rbase + 8 * g + 4 + rsub, cbyte)));
-                const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
-                bf[ni] = (u32x4){l2.x, l2.y, h2.x, h2.y};
-            }
+            for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+                for (int mi = 0; mi < 2; ++mi) {
+                    f32x4& cc = acc[ky * 3 + kx][mi][ni];
                     if constexpr (DType<T>::id == DBX_F16)
-                        acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mi]), __builtin_bit_cast(f16x8, bf[ni]), acc[t][mi][ni], 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mi]), __builtin_bit_cast(f16x8, bf[kx]), cc, 0, 0, 0);
                     else
-                        acc[t][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[ni]), acc[t][mi][ni], 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[kx]), cc, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (u < 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
         }
         if (s + 1 < nsteps) { if (do_bias) bias_acc(); lstore(buf ^ 1); }
         __syncthreads();
@@ -913,7 +935,15 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
         if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wgrad3x3_c8_kernel<T>), dim3(p.splits), dim3(256), 0, s, a);
     } else if (p.alltaps) {
         if constexpr (sizeof(T) == 2)
-            hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), 0, s, a);
+            {
+                constexpr int smem = 2 * (32 * 128 + 3 * 36 * 128);
+                static bool attr_set = false;
+                if (!attr_set) {
+                    DBX_HIP(hipFuncSetAttribute((const void*)wgrad3x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), smem, s, a);
+            }
     } else if (p.row3) {
         if constexpr (sizeof(T) == 2) {
             constexpr int smem = 2 * (64 * 256 + 68 * 256);
