@@ -822,37 +822,61 @@ __global__ __launch_bounds__(256) void wgrad3x3_c8_kernel(const WgradArgs a) {
 // dw[co][ci][tap] = sum_s partial[s][co][tap][ci], db[co] = sum_s bpartial[s][co].  Deterministic: 4 lanes own one output
 // element, lane g sums splits g, g+4, ... in ascending order, and the four partial sums are combined in the fixed order
 // ((s0+s1)+(s2+s3)).  Consecutive elements of a slab row map to consecutive 4-lane groups (coalesced 16-element reads).
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits, int co,
-                                    int ci, int taps, int co_pad, int ci_pad, float* __restrict__ dw, float* __restrict__ db,
-                                    int accumulate) {
-    const long long total = (long long)co * taps * ci;
+// Fixed-order split-K reduction: partial [splits][co_pad][taps][ci_pad] -> dw [co][ci][taps] (OIHW), bpartial -> db.
+// A lane owns four consecutive ci (one 16-byte load per split); the four waves of a workgroup each sum every fourth split
+// with independent loads in flight and are combined in a fixed order through LDS, so results are bitwise repeatable.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits,
+                                                           int co, int ci, int taps, int co_pad, int ci_pad, float* __restrict__ dw,
+                                                           float* __restrict__ db, int accumulate) {
+    const int c4n = ci_pad >> 2;                                       // 4-float groups per (co, tap) row
+    const long long total4 = (long long)co * taps * c4n;
+    const long long nb = (co + 3) / 4;                                 // bias groups (four couts each)
     const long long slab = (long long)co_pad * taps * ci_pad;
     const int g = threadIdx.x >> 6;                                   // split group 0..3 (one wave each)
     const int e = threadIdx.x & 63;
-    __shared__ float red[4][64];
-    for (long long base = (long long)blockIdx.x * 64; base < total + co; base += (long long)gridDim.x * 64) {
+    __shared__ f32x4 red[4][64];
+    for (long long base = (long long)blockIdx.x * 64; base < total4 + nb; base += (long long)gridDim.x * 64) {
         const long long i = base + e;
-        float s = 0.f;
-        long long dst = -1;
-        bool is_b = false;
-        if (i < total) {
-            const int c = (int)(i % ci);
-            const int t = (int)((i / ci) % taps);
-            const int o = (int)(i / ((long long)ci * taps));
-            const long long src = ((long long)o * taps + t) * ci_pad + c;
-            for (int k = g; k < splits; k += 4) s += partial[k * slab + src];
-            dst = ((long long)o * ci + c) * taps + t;
-        } else if (i < total + co && db) {
-            const int o = (int)(i - total);
-            for (int k = g; k < splits; k += 4) s += bpartial[(long long)k * co_pad + o];
-            dst = o; is_b = true;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int o = 0, t = 0, c = 0;
+        const bool is_w = i < total4, is_b = !is_w && i < total4 + nb && db != nullptr;
+        if (is_w) {
+            const int cg = (int)(i % c4n);
+            t = (int)((i / c4n) % taps);
+            o = (int)(i / ((long long)c4n * taps));
+            c = cg * 4;
+            const float* src = partial + ((long long)o * taps + t) * ci_pad + c;
+            int k = g;
+            for (; k + 12 < splits; k += 16) {                         // four independent 16-byte loads in flight
+                const f32x4 v0 = *(const f32x4*)(src + (long long)k * slab), v1 = *(const f32x4*)(src + (long long)(k + 4) * slab);
+                const f32x4 v2 = *(const f32x4*)(src + (long long)(k + 8) * slab), v3 = *(const f32x4*)(src + (long long)(k + 12) * slab);
+                s += (v0 + v1) + (v2 + v3);
+            }
+            for (; k < splits; k += 4) s += *(const f32x4*)(src + (long long)k * slab);
+        } else if (is_b) {
+            o = (int)(i - total4) * 4;
+            for (int k = g; k < splits; k += 4) {
+                const float* bp = bpartial + (long long)k * co_pad + o;      // co_pad is a multiple of 64: in bounds
+                s += (f32x4){bp[0], bp[1], bp[2], bp[3]};
+            }
         }
         red[g][e] = s;
         __syncthreads();
-        if (g == 0 && dst >= 0) {
-            const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
-            float* out = is_b ? db : dw;
-            out[dst] = accumulate ? out[dst] + v : v;
+        if (g == 0 && (is_w || is_b)) {
+            const f32x4 v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            if (is_w) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < ci) {
+                        float* out = dw + ((long long)o * ci + c + j) * taps + t;
+                        *out = accumulate ? *out + vv[j] : vv[j];
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (o + j < co) db[o + j] = accumulate ? db[o + j] + vv[j] : vv[j];
+            }
         }
         __syncthreads();
     }
@@ -970,7 +994,7 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
         else hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, dim3(256), 0, s, a);
     }
     DBX_LAUNCH_CHECK();
-    const long long total = (long long)co * p.taps * ci + co;
+    const long long total = (long long)co * p.taps * (p.ci_pad / 4) + (co + 3) / 4;
     int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, co, ci, p.taps, p.co_pad,
                        p.ci_pad, dw, db, accumulate);
