@@ -96,6 +96,30 @@ def pmc_traffic(family):
     return None
 
 
+def measured_peaks(dev, dtype):
+    """Achievable peaks measured on this box: a large library GEMM (hipBLASLt through torch.mm) in the
+    compute dtype and a streaming device copy.  Reference points for the roofline fractions, never part of the product path."""
+    tdt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[dtype]
+    m = 8192
+    a = torch.randn(m, m, device=dev).to(tdt); b = torch.randn(m, m, device=dev).to(tdt)
+    for _ in range(3):
+        torch.mm(a, b)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        torch.mm(a, b)
+    e1.record(); torch.cuda.synchronize()
+    gemm = 10 * 2.0 * m ** 3 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0.record()
+    for _ in range(10):
+        dst.copy_(src)
+    e1.record(); torch.cuda.synchronize()
+    copy = 10 * 2.0 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return {'library_gemm_8192_tflops': round(gemm, 1), 'stream_copy_GBps': round(copy, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -197,6 +221,9 @@ def main():
             'step_tflops_per_gpu': round(n * STEP_GFLOP[kind] / (ms * 1e-3) / 1e3, 1),
             'roofline': roof,
         }
+        mp = measured_peaks(dev, args.dtype)
+        roof['measured_peak'] = mp
+        roof['frac_of_measured_gemm'] = round(ach / mp['library_gemm_8192_tflops'], 4)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(kind, args.cpu_seconds)
     barrier()
