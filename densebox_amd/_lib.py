@@ -51,6 +51,7 @@ SIGNATURES = {
     'dbx_device_arch': (C.c_int, [C.c_int]),
     'dbx_conv_packed_elems': (_I64, [_PC]),
     'dbx_conv_forward': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _VP, _I32, _VP]),
+    'dbx_conv_forward_split': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _PV, _PV, _I32, _I32, _VP]),
     'dbx_pack_weight': (C.c_int, [_I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
     'dbx_fold_heads': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP]),
     'dbx_pack_multi': (C.c_int, [_I32, _VP, _I32, _I64, _VP]),

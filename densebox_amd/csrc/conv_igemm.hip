@@ -39,6 +39,10 @@ struct ConvArgs {
     int epi;
     int dm_ld;
     unsigned drop_seed;
+    // optional second destination: couts >= split_c (a multiple of the N tile) go to y2 with their own epilogue / gate
+    char* y2; const char* gate2;
+    int y2_hp, y2_wp, y2_ld, y2_pad, g2_hp, g2_wp, g2_ld, g2_pad;
+    int split_c, epi2, cout_valid2;
 };
 
 // XOR mask (in 16-byte chunks) of a tile row, applied on the LDS-DMA source side and on the fragment reads.
@@ -81,12 +85,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI
     // ---- epilogue: lane holds couts cb + ni*16 + (l>>4)*4 + {0..3} of pixel mb + mi*16 + (l&15)
     const int cb = n0 + wn_off + (lane >> 4) * 4;
     const int mb = m0 + wm_off + (lane & 15);
-    const int epi = a.epi;
+    const bool second = a.split_c > 0 && n0 >= a.split_c;               // uniform per workgroup
+    const int epi = second ? a.epi2 : a.epi;
+    char* const ybase = second ? a.y2 : a.y;
+    const char* const gbase = second ? a.gate2 : a.gate;
+    const int y_hp = second ? a.y2_hp : a.y_hp, y_wp = second ? a.y2_wp : a.y_wp, y_ld = second ? a.y2_ld : a.y_ld, y_pad = second ? a.y2_pad : a.y_pad;
+    const int g_hp = second ? a.g2_hp : a.g_hp, g_wp = second ? a.g2_wp : a.g_wp, g_ld = second ? a.g2_ld : a.g_ld, g_pad = second ? a.g2_pad : a.g_pad;
+    const int cshift = second ? a.split_c : 0, cvalid = second ? a.split_c + a.cout_valid2 : a.cout_valid;
     f32x4 hbias[HOIST ? NI : 1];
     if constexpr (HOIST) {
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni)
-            hbias[ni] = ((epi & DBX_EPI_BIAS) && cb + ni * 16 < a.cout_valid) ? *(const f32x4*)(a.bias + cb + ni * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            hbias[ni] = ((epi & DBX_EPI_BIAS) && cb + ni * 16 < cvalid) ? *(const f32x4*)(a.bias + cb + ni * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // pixel coordinates: divided out once, then advanced 16 pixels per fragment row
     int n = mb / a.HoWo, r = mb - n * a.HoWo;
@@ -106,12 +116,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI
             }
         }
         if (m >= a.M) continue;
-        const size_t ypix = ((size_t)(n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
-        const size_t gpix = ((size_t)(n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld;
+        const size_t ypix = ((size_t)(n * y_hp + oy + y_pad) * y_wp + (ox + y_pad)) * (size_t)y_ld;
+        const size_t gpix = ((size_t)(n * g_hp + oy + g_pad) * g_wp + (ox + g_pad)) * (size_t)g_ld;
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int c = cb + ni * 16;
-            if (c >= a.cout_valid) continue;
+            if (c >= cvalid) continue;
             f32x4 v = acc[ni][mi];
             if constexpr (HOIST) {
                 v += hbias[ni];
@@ -123,7 +133,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
             if (epi & DBX_EPI_GATE) {
-                const T* g = (const T*)a.gate + gpix + c;
+                const T* g = (const T*)gbase + gpix + (c - cshift);
                 v.x = to_f32(g[0]) > 0.f ? v.x : 0.f; v.y = to_f32(g[1]) > 0.f ? v.y : 0.f;
                 v.z = to_f32(g[2]) > 0.f ? v.z : 0.f; v.w = to_f32(g[3]) > 0.f ? v.w : 0.f;
             }
@@ -138,7 +148,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI
                 v.z = (kb & 4u) ? v.z * 2.f : 0.f; v.w = (kb & 8u) ? v.w * 2.f : 0.f;
             }
             if (epi & DBX_EPI_F32_NCHW) {
-                float* o = (float*)a.y + ((size_t)n * a.cout_valid + c) * a.HoWo + r;
+                float* o = (float*)ybase + ((size_t)n * a.cout_valid + c) * a.HoWo + r;
                 const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -147,7 +157,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI
                         else o[(size_t)j * a.HoWo] = vv[j];
                     }
             } else {
-                T* o = (T*)a.y + ypix + c;
+                T* o = (T*)ybase + ypix + (c - cshift);
                 if (epi & DBX_EPI_ACCUM) {
                     v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]);
                 }
@@ -684,7 +694,8 @@ static int conv_variant() {          // DBX_CONV_VARIANT=1 forces the register-s
 
 template <typename T>
 static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void* w, const float* bias,
-                          const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int dm_ld, hipStream_t s) {
+                          const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int dm_ld, hipStream_t s,
+                          const dbx_view* y2 = nullptr, const dbx_view* gate2 = nullptr, int split_c = 0, int epi2 = 0) {
     constexpr int ES = sizeof(T);
     const int ho = x->h + 2 * d->cpad - d->kh + 1, wo = x->w + 2 * d->cpad - d->kw + 1;
     DBX_REQUIRE(ho == y->h && wo == y->w && x->n == y->n, "conv: output %dx%d does not match %dx%d", y->h, y->w, ho, wo);
@@ -719,6 +730,24 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.ksteps = a.ktot_bytes / 128;
     a.cout_valid = y->c;
     a.epi = d->epilogue; a.dm_ld = dm_ld; a.drop_seed = d->drop_seed;
+    a.y2 = nullptr; a.gate2 = nullptr; a.split_c = 0; a.epi2 = 0; a.cout_valid2 = 0;
+    a.y2_hp = a.y2_wp = a.y2_ld = a.y2_pad = a.g2_hp = a.g2_wp = a.g2_ld = a.g2_pad = 0;
+    if (y2) {
+        // split destination: 1x1 GEMM on the 256-wide DMA tiles only
+        DBX_REQUIRE(sizeof(T) == 2 && d->kh == 1 && d->kw == 1 && !smallc && split_c > 0 && split_c % 256 == 0 && y->c == split_c &&
+                    d->cout_pad % 256 == 0 && split_c + y2->c <= d->cout_pad && y2->c % 4 == 0 && y2->h == y->h && y2->w == y->w && y2->n == y->n &&
+                    !(d->epilogue & DBX_EPI_F32_NCHW) && !(epi2 & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK | DBX_EPI_DROPHASH | DBX_EPI_BIAS)),
+                    "conv split: needs a 1x1 16-bit GEMM, split_c = y.c a multiple of 256, plain/gate/accumulate second epilogue");
+        DBX_REQUIRE(((y2->c_off * ES) % 8) == 0 && (y2->ld * ES) % 8 == 0, "conv split: y2 alignment");
+        if (epi2 & DBX_EPI_GATE) DBX_REQUIRE(gate2 && gate2->h == y2->h && gate2->w == y2->w && gate2->c >= y2->c, "conv split: bad gate2 view");
+        a.y2 = (char*)y2->ptr + (size_t)y2->c_off * ES;
+        a.y2_hp = y2->h + 2 * y2->pad; a.y2_wp = y2->w + 2 * y2->pad; a.y2_ld = y2->ld; a.y2_pad = y2->pad;
+        if (gate2) {
+            a.gate2 = (const char*)gate2->ptr + (size_t)gate2->c_off * ES;
+            a.g2_hp = gate2->h + 2 * gate2->pad; a.g2_wp = gate2->w + 2 * gate2->pad; a.g2_ld = gate2->ld; a.g2_pad = gate2->pad;
+        }
+        a.split_c = split_c; a.epi2 = epi2; a.cout_valid2 = y2->c;
+    }
     DBX_REQUIRE(a.M > 0 && (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < (int64_t)1 << 40, "conv: empty or oversized input");
 
     // 3x3 / pad 1 on congruent frames (x.pad == 1), 16-bit, plain NHWC epilogue: the band kernel over the linearised frame
@@ -750,6 +779,11 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
             return launch_conv_dma<T, 256, 64, 128, 3, 8, 1>(a, s);
         }
+        if (y2) {                                                                    // split destination: 256x256 tiles over both
+            a.ntile_n = (split_c + y2->c + 255) / 256;
+            a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
+            return launch_conv_dma<T, 256, 256, 64, 4, 2, 4>(a, s);
+        }
         if (d->cout_pad % 256 == 0 && y->c % 256 == 0 && conv_variant() != 2) {      // wide layers: 256x256 tile
             a.ntile_n = y->c / 256;
             a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
@@ -777,6 +811,14 @@ extern "C" int dbx_conv_forward(const dbx_conv_desc* d, const dbx_view* x, const
                                 void* stream) {
     if (!d || !x || !y || !w_packed) { dbx_set_error("conv: null argument"); return DBX_ERR_ARG; }
     DBX_DISPATCH_DTYPE(d->dtype, conv_forward_t, d, x, w_packed, bias, y, gate, dropmask, dropmask_ld, (hipStream_t)stream);
+}
+
+extern "C" int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
+                                      const dbx_view* y, const dbx_view* gate, const dbx_view* y2, const dbx_view* gate2,
+                                      int32_t split_c, int32_t epilogue2, void* stream) {
+    if (!d || !x || !y || !y2 || !w_packed) { dbx_set_error("conv split: null argument"); return DBX_ERR_ARG; }
+    if (d->dtype == DBX_F32) { dbx_set_error("conv split: 16-bit types only"); return DBX_ERR_DTYPE; }
+    DBX_DISPATCH_DTYPE(d->dtype, conv_forward_t, d, x, w_packed, bias, y, gate, nullptr, 0, (hipStream_t)stream, y2, gate2, split_c, epilogue2);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing

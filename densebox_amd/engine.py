@@ -606,9 +606,24 @@ class Engine:
         w1t = self._w_heads1_bwd(dt)                          # [768 rows][512*nh]
         row_bytes = 512 * nh * _lib.ESIZE[dt]
         c34 = B['fusion'].view(512, 256)
-        self._conv(dt, B['d_hid'].view(), B['d_ups'].view(), w1t, None, 1, 1, 0, 512 * nh, 512, 0)
-        self._conv(dt, B['d_hid'].view(), B['d_c34'].view(), w1t[512 * row_bytes:], None, 1, 1, 0, 512 * nh, 256,
-                   _lib.EPI_GATE, gate=c34)
+        if dt != _lib.F32:
+            # one pass over d_hid for both branches of the concat: couts 0..511 -> d_ups, 512..767 -> d_c34 (ReLU-gated)
+            d = ConvDesc(dt, 1, 1, 0, 512 * nh, 768, 0, 0)
+            prof = self.profile
+            if prof is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            check(L.dbx_conv_forward_split(C.byref(d), C.byref(B['d_hid'].view()), ptr(w1t), None, C.byref(B['d_ups'].view()), None,
+                                           C.byref(B['d_c34'].view()), C.byref(c34), 512, _lib.EPI_GATE, s))
+            if prof is not None:
+                ev1.record()
+                hv = B['d_hid'].view()
+                prof.append({'kernel': 'conv_igemm_dma_kernel<%s,256,256>' % ('f16', 'bf16', 'f32')[dt],
+                             'flops': 2.0 * hv.n * hv.h * hv.w * 512 * nh * 768, 'start': ev0, 'end': ev1})
+        else:
+            self._conv(dt, B['d_hid'].view(), B['d_ups'].view(), w1t, None, 1, 1, 0, 512 * nh, 512, 0)
+            self._conv(dt, B['d_hid'].view(), B['d_c34'].view(), w1t[512 * row_bytes:], None, 1, 1, 0, 512 * nh, 256,
+                       _lib.EPI_GATE, gate=c34)
         check(L.dbx_upsample_bilinear_bwd(dt, C.byref(B['d_ups'].view()), C.byref(B['d_a44'].view()),
                                           C.byref(B['a44'].view()), s))
 

@@ -82,6 +82,13 @@ int64_t dbx_conv_packed_elems(const dbx_conv_desc* d);
 int dbx_conv_forward(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
                      const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int32_t dropmask_ld,
                      void* stream);
+/* 1x1 GEMM (16-bit types) with a split destination: couts [0, split_c) go to y with d->epilogue / gate, couts
+ * [split_c, split_c + y2->c) to y2 with epilogue2 (plain, GATE and/or ACCUM) / gate2.  split_c = y->c, a multiple of 256.
+ * Used for the data gradient of the fusion concat (torch.cat, DenseBox.py:219): one pass over the 2048-channel hidden
+ * gradient feeds both the up-sampled conv4_4 branch and the conv3_4 branch. */
+int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
+                           const dbx_view* y, const dbx_view* gate, const dbx_view* y2, const dbx_view* gate2,
+                           int32_t split_c, int32_t epilogue2, void* stream);
 
 /* fp32 OIHW [co][ci][kh][kw] -> packed compute-dtype weight.
  * mode 0: forward            wp[co][tap][ci]            = w[co][ci][tap]
