@@ -473,6 +473,197 @@ extern "C" int dbx_head2_dgrad(int32_t dtype, const dbx_view* d_out, const float
     DBX_DISPATCH_DTYPE(dtype, head2_dgrad_t, d_out, w2, k, nh, d_hid, dropmask, dropmask_ld, use_hash, (unsigned)drop_seed, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------- stage-2 head weight gradient
+// dW2[head][j][c] = sum_pixels d_out[pixel][head slot][j] * hid[pixel][512*head + c]  (k <= 8 outputs per head), and
+// db2[head][j] = sum_pixels d_out[..][j].  Rank-k updates against the 944 MB hidden map: one streaming pass for all
+// heads (the per-head GEMM tiles would stride through it five times with 64x64 tiles that are 88 % padding).  Lanes are
+// laid out as in head2_dgrad (one 16-byte chunk of one head's 512 channels per lane, whole pixels per workgroup);
+// every lane keeps its 8 x V accumulator block in registers, workgroups own fixed image rows, and the per-workgroup
+// partials are summed in a fixed order by head2_wgrad_reduce_kernel (bitwise repeatable).
+template <typename T>
+__global__ __launch_bounds__(512) void head2_wgrad_kernel(FrameGeo dout, FrameGeo hid, int nh, int slot, float* __restrict__ partial,
+                                                          float* __restrict__ bpartial) {
+    constexpr int V = Vec<T>::N;
+    constexpr int LPH = 512 / V;
+    const int lph_all = LPH * nh;
+    const int ppb = blockDim.x / lph_all > 0 ? blockDim.x / lph_all : 1;
+    const int sub = threadIdx.x % lph_all, grp = threadIdx.x / lph_all;
+    const int hd = sub / LPH, c0 = (sub % LPH) * V;
+    const bool active = threadIdx.x < ppb * lph_all;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));        // pairs: the accumulation compiles to v_pk_fma_f32
+    f32x2 acc[8][V / 2];
+    float bs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bs[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < V / 2; ++i) acc[j][i] = (f32x2){0.f, 0.f};
+    }
+    // a workgroup owns a contiguous range of pixels; each lane group walks it with stride ppb, the next pixel's two
+    // 16-byte loads in flight while the current one is accumulated (the loop is latency-bound otherwise)
+    const long long npix = (long long)hid.n * hid.h * hid.w;
+    const long long per = (npix + gridDim.x - 1) / gridDim.x;
+    const long long p0 = (long long)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+    if (active && p0 + grp < p1) {
+        long long p = p0 + grp;
+        int n = (int)(p / ((long long)hid.h * hid.w));
+        int rem = (int)(p - (long long)n * hid.h * hid.w);
+        int py = rem / hid.w, px = rem - py * hid.w;
+        // raw 16-byte chunks of three pixels ahead stay in flight (two loads each); converted when consumed
+        constexpr int D = 3;
+        u32x4 graw[D], ghi[D], hraw[D];                                   // ghi: channels 4..7 of an f32 slot
+        auto fetch = [&](int d) {
+            const T* g = (const T*)dout.base + geo_pix(dout, n, py, px) + hd * slot;
+            graw[d] = *(const u32x4*)g;
+            if constexpr (sizeof(T) == 4) ghi[d] = *(const u32x4*)(g + 4);
+            hraw[d] = *(const u32x4*)((const T*)hid.base + geo_pix(hid, n, py, px) + hd * 512 + c0);
+        };
+        auto advance = [&]() {
+            p += ppb; px += ppb;
+            while (px >= hid.w) { px -= hid.w; if (++py == hid.h) { py = 0; ++n; } }
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (p < p1) fetch(d);
+            advance();
+        }
+        long long pc = p0 + grp;                                         // pixel being consumed
+        while (pc < p1) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                if (pc < p1) {
+                    float gj[8], h[V];
+                    if constexpr (sizeof(T) == 2) {
+                        const T* ge = (const T*)&graw[d];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) gj[j] = to_f32(ge[j]);
+                    } else {
+                        const float* ge = (const float*)&graw[d];
+                        const float* gh = (const float*)&ghi[d];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { gj[j] = ge[j]; gj[j + 4] = gh[j]; }
+                    }
+                    const T* he = (const T*)&hraw[d];
+#pragma unroll
+                    for (int i = 0; i < V; ++i) h[i] = to_f32(he[i]);
+                    if (p < p1) fetch(d);
+                    advance();
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        bs[j] += gj[j];
+                        const f32x2 g2 = {gj[j], gj[j]};
+#pragma unroll
+                        for (int i = 0; i < V / 2; ++i) acc[j][i] = g2 * (f32x2){h[2 * i], h[2 * i + 1]} + acc[j][i];
+                    }
+                }
+                pc += ppb;
+            }
+        }
+    }
+    // combine the ppb pixel groups of this workgroup in a fixed order through LDS, then one partial block per workgroup
+    __shared__ float red[512 * 9];
+    float* P = partial + (size_t)blockIdx.x * nh * 8 * 512;
+    for (int j = 0; j < 8; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < V; ++i) red[threadIdx.x * V + i] = acc[j][i >> 1][i & 1];
+        if (V == 8) {}                                                   // (red holds 512 * V floats at most: V <= 8)
+        __syncthreads();
+        if (threadIdx.x < lph_all) {
+            float o[V];
+#pragma unroll
+            for (int i = 0; i < V; ++i) o[i] = 0.f;
+            for (int q = 0; q < ppb; ++q)
+#pragma unroll
+                for (int i = 0; i < V; ++i) o[i] += red[(q * lph_all + sub) * V + i];
+#pragma unroll
+            for (int i = 0; i < V; ++i) P[((size_t)hd * 8 + j) * 512 + c0 + i] = o[i];
+        }
+    }
+    __syncthreads();
+    if (active && c0 == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[(grp * 4 + hd) * 8 + j] = bs[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < nh * 8) {
+        const int hh = threadIdx.x / 8, j = threadIdx.x % 8;
+        float o = 0.f;
+        for (int q = 0; q < ppb; ++q) o += red[(q * 4 + hh) * 8 + j];
+        bpartial[(size_t)blockIdx.x * 32 + hh * 8 + j] = o;
+    }
+}
+struct Head2Out { float* dw[4]; float* db[4]; int k[4]; };
+// 64 consecutive (head, j, c) elements per workgroup; wave w of 16 sums partial blocks w, w+16, ... (four loads in flight),
+// the 16 wave sums are added in a fixed order.
+__global__ __launch_bounds__(1024) void head2_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int nblk,
+                                                                   int nh, Head2Out o) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ne = nh * 8 * 512, e = blockIdx.x * 64 + lane;
+    const size_t stride = (size_t)nh * 4096;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < ne) {
+        int b = w;
+        for (; b + 48 < nblk; b += 64) {
+            s0 += partial[(size_t)b * stride + e]; s1 += partial[(size_t)(b + 16) * stride + e];
+            s2 += partial[(size_t)(b + 32) * stride + e]; s3 += partial[(size_t)(b + 48) * stride + e];
+        }
+        for (; b < nblk; b += 16) s0 += partial[(size_t)b * stride + e];
+    } else if (e < ne + nh * 8) {
+        const int q = e - ne;
+        for (int b = w; b < nblk; b += 16) s0 += bpartial[(size_t)b * 32 + (q / 8) * 8 + (q % 8)];
+    }
+    red[w][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (w == 0) {
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += red[q][lane];
+        if (e < ne) {
+            const int hd = e / (8 * 512), j = (e / 512) % 8, c = e % 512;
+            if (j < o.k[hd]) o.dw[hd][j * 512 + c] = sum;
+        } else if (e < ne + nh * 8) {
+            const int q = e - ne, hd = q / 8, j = q % 8;
+            if (j < o.k[hd] && o.db[hd]) o.db[hd][j] = sum;
+        }
+    }
+}
+static int head2_wgrad_blocks(int rows) { return rows < 512 ? rows : 512; }
+extern "C" int64_t dbx_head2_wgrad_scratch_bytes(int32_t nh, int32_t rows) {
+    return (int64_t)head2_wgrad_blocks(rows) * ((int64_t)nh * 8 * 512 + 32) * 4;
+}
+template <typename T>
+static int head2_wgrad_t(const dbx_view* dout, const dbx_view* hid, const int32_t* k, int nh, float* const* dw, float* const* db,
+                         void* scratch, hipStream_t s) {
+    VIEW_VEC_CHECK(T, hid, "head2_wgrad hid");
+    DBX_REQUIRE(nh >= 1 && nh <= 4 && hid->c == 512 * nh && dout->c % nh == 0 && dout->c / nh >= 8, "head2_wgrad: nh in 1..4, hid of 512*nh channels, d_out of nh slots >= 8 channels");
+    DBX_REQUIRE(dout->n == hid->n && dout->h == hid->h && dout->w == hid->w, "head2_wgrad: shape mismatch");
+    DBX_REQUIRE(((size_t)dout->ptr % 16) == 0 && (dout->ld * sizeof(T)) % 16 == 0 && (dout->c_off * sizeof(T)) % 16 == 0 &&
+                    ((dout->c / nh) * sizeof(T)) % 16 == 0, "head2_wgrad: d_out alignment");
+    Head2Out o;
+    for (int i = 0; i < 4; ++i) {
+        o.dw[i] = i < nh ? dw[i] : nullptr; o.db[i] = (i < nh && db) ? db[i] : nullptr; o.k[i] = i < nh ? k[i] : 0;
+        if (i < nh) DBX_REQUIRE(k[i] >= 1 && k[i] <= 8 && dw[i], "head2_wgrad: k in 1..8");
+    }
+    const int lph_all = (512 / Vec<T>::N) * nh;
+    const int threads = lph_all <= 256 ? 256 : 512;
+    const int blocks = head2_wgrad_blocks(hid->n * hid->h);
+    float* partial = (float*)scratch;
+    float* bpartial = partial + (size_t)blocks * nh * 8 * 512;
+    hipLaunchKernelGGL(head2_wgrad_kernel<T>, dim3(blocks), dim3(threads), 0, s, make_geo<T>(dout), make_geo<T>(hid), nh, dout->c / nh, partial, bpartial);
+    DBX_LAUNCH_CHECK();
+    const int total = nh * 8 * 512 + nh * 8;
+    hipLaunchKernelGGL(head2_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, s, partial, bpartial, blocks, nh, o);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_head2_wgrad(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const int32_t* k, int32_t nh,
+                               float* const* dw, float* const* db, void* scratch, void* stream) {
+    if (!d_out || !hid || !k || !dw || !scratch) { dbx_set_error("head2_wgrad: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(dtype, head2_wgrad_t, d_out, hid, k, nh, dw, db, scratch, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------- multi-tensor weight packing
 // One launch re-packs every parameter after an optimizer step (fp32 OIHW -> compute-dtype GEMM layouts, both the forward
 // and the transposed/flipped dgrad copy) and refreshes the padded fp32 bias vectors.  Same element mapping as

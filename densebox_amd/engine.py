@@ -583,8 +583,26 @@ class Engine:
             check(L.dbx_framed_add_ch(dt, C.byref(B['d_rf_in'].view()), 4, 1, C.byref(slot['det']), 0, s))
 
         # ---- heads: 512 -> k (per head), dropout, then the shared 768 -> 512*nh GEMM
-        for i, (stem, k) in enumerate(heads):
-            conv_bwd('conv5_2_' + stem, slot[stem], B['hid'].view(512 * i, 512), 1, 1, 0, k, 512)
+        # stage-2 weight/bias gradients of all heads: one streaming pass over the hidden map
+        hv = B['hid'].view()
+        need = L.dbx_head2_wgrad_scratch_bytes(nh, hv.n * hv.h)
+        if getattr(self, '_h2_scratch', None) is None or self._h2_scratch.numel() < need:
+            self._h2_scratch = torch.empty(int(need), dtype=torch.uint8, device=dev)
+        dw2 = [new_grad('conv5_2_%s.weight' % st) for st, _ in heads]
+        db2 = [new_grad('conv5_2_%s.bias' % st) for st, _ in heads]
+        prof = self.profile
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        check(L.dbx_head2_wgrad(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_int32 * nh)(*[k for _, k in heads]), nh,
+                                (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
+                                ptr(self._h2_scratch), s))
+        if prof is not None:
+            ev1.record()
+            prof.append({'kernel': 'head2_wgrad_kernel<%s>' % ('f16', 'bf16', 'f32')[dt],
+                         'flops': 2.0 * hv.n * hv.h * hv.w * 512 * sum(k for _, k in heads), 'start': ev0, 'end': ev1})
+        if sink is not None:
+            sink.ready(['conv5_2_%s.weight' % st for st, _ in heads] + ['conv5_2_%s.bias' % st for st, _ in heads])
         w2s = [self._param('conv5_2_%s.weight' % st).detach() for st, _ in heads]      # fp32 [k,512,1,1]
         check(L.dbx_head2_dgrad(dt, C.byref(B['d_out'].view()), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]),
                                 (C.c_int32 * nh)(*[k for _, k in heads]), nh, C.byref(B['d_hid'].view()),

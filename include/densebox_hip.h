@@ -109,6 +109,13 @@ int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, int64_t max_e
 int dbx_head2_dgrad(int32_t dtype, const dbx_view* d_out, const float* const* w2, const int32_t* k, int32_t nh,
                     const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash, uint32_t drop_seed,
                     void* stream);
+/* Weight/bias gradients of the same stage-2 head convs in one streaming pass over the hidden map:
+ * dw[h] fp32 [k[h]][512] (OIHW of the 1x1 conv), db[h] fp32 [k[h]] (may be NULL).  scratch: dbx_head2_wgrad_scratch_bytes
+ * (rows = N * H of the maps).  Replaces autograd's weight gradient of `nn.Conv2d(512, k, 1)` at DenseBox.py:161,168,
+ * :458-461, :720-726. */
+int64_t dbx_head2_wgrad_scratch_bytes(int32_t nh, int32_t rows);
+int dbx_head2_wgrad(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const int32_t* k, int32_t nh,
+                    float* const* dw, float* const* db, void* scratch, void* stream);
 
 /* eval-mode folding of one head, Conv1x1(768->512) -> Dropout(identity) -> Conv1x1(512->k), into a single 768->k map
  * (no non-linearity in between, DenseBox.py:158-162): w_out[k][768] = w2 w1, b_out[k] = w2 b1 + b2 (all fp32) */
