@@ -106,3 +106,79 @@ def test_conv_wgrad_kernel(case, dtn):
     # accumulate flag
     check(L.dbx_conv_wgrad(dt, C.byref(dzv), C.byref(xv), k, k, pad, co, ci, ptr(dw), ptr(db), ptr(sc), 1, stream_ptr()))
     assert (dw - 2 * wref.grad).abs().max().item() <= 4e-4 * scale + 2e-4
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+def test_conv_forward_split_destination(dtn):
+    """dbx_conv_forward_split == two separate 1x1 GEMMs (second destination ReLU-gated), bit for bit."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    n, h, w, ci, c1, c2 = 2, 13, 17, 512, 512, 256
+    g = torch.Generator(device='cpu').manual_seed(7)
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(c1 + c2, ci, 1, 1, generator=g) * (1.0 / ci) ** 0.5).cuda()
+    gate_src = torch.randn(n, c2, h, w, generator=g).cuda()
+    fx, tx, xv = framed(x, 1, tdt)
+    fg, tg, gv = framed(gate_src, 2, tdt)
+    wp = pack(L, dt, wt, ci, c1 + c2)
+    row_bytes = ci * _lib.ESIZE[dt]
+    # reference: two launches
+    fa, ta, av = framed(torch.zeros(n, c1, h, w), 0, tdt)
+    fb, tb, bv = framed(torch.zeros(n, c2, h, w), 1, tdt)
+    d1 = ConvDesc(dt, 1, 1, 0, ci, c1, 0)
+    check(L.dbx_conv_forward(C.byref(d1), C.byref(xv), ptr(wp), None, C.byref(av), None, None, 0, stream_ptr()))
+    d2 = ConvDesc(dt, 1, 1, 0, ci, c2, _lib.EPI_GATE)
+    check(L.dbx_conv_forward(C.byref(d2), C.byref(xv), ptr(wp[c1 * row_bytes:]), None, C.byref(bv), C.byref(gv), None, 0, stream_ptr()))
+    # split launch
+    fa2, ta2, av2 = framed(torch.zeros(n, c1, h, w), 0, tdt)
+    fb2, tb2, bv2 = framed(torch.zeros(n, c2, h, w), 1, tdt)
+    d = ConvDesc(dt, 1, 1, 0, ci, c1 + c2, 0)
+    check(L.dbx_conv_forward_split(C.byref(d), C.byref(xv), ptr(wp), None, C.byref(av2), None, C.byref(bv2), C.byref(gv), c1,
+                                   _lib.EPI_GATE, stream_ptr()))
+    assert torch.equal(ta, ta2) and torch.equal(tb, tb2)
+    assert float(ta2.float().abs().sum()) > 0 and float(tb2.float().abs().sum()) > 0
+    # and against torch on the rounded operands
+    ref = F.conv2d(x.to(tdt).float(), wt.to(tdt).float())
+    got1 = ta2.permute(0, 3, 1, 2).float()
+    got2 = tb2[:, 1:1 + h, 1:1 + w].permute(0, 3, 1, 2).float()
+    tol = 2e-2 if dtn == 'bf16' else 3e-3
+    assert torch.allclose(got1, ref[:, :c1], rtol=tol, atol=tol)
+    assert torch.allclose(got2, ref[:, c1:] * (gate_src.to(tdt).float() > 0), rtol=tol, atol=tol)
+    # argument validation: the split must sit on a 256-channel tile boundary
+    bad = View(C.c_void_p(ta2.data_ptr()), n, h, w, 0, c1, 0, 128)
+    assert L.dbx_conv_forward_split(C.byref(d), C.byref(xv), ptr(wp), None, C.byref(bad), None, C.byref(bv2), C.byref(gv), 128,
+                                    _lib.EPI_GATE, stream_ptr()) != 0
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16', 'f32'])
+@pytest.mark.parametrize('ks', [(1, 4), (1, 4, 4, 8), (2, 4, 4)])
+def test_head2_wgrad_kernel(ks, dtn):
+    """One streaming pass == per-head einsum of d_out x hid on the rounded operands (fp32 accumulation order differs)."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    nh, n, h, w, slot = len(ks), 3, 11, 19, 8
+    g = torch.Generator(device='cpu').manual_seed(3 + nh)
+    hid = torch.randn(n, 512 * nh, h, w, generator=g).cuda()
+    dout = torch.zeros(n, slot * nh, h, w)
+    for i, k in enumerate(ks):
+        dout[:, slot * i:slot * i + k] = torch.randn(n, k, h, w, generator=g)
+    dout = dout.cuda()
+    fh, th, hv = framed(hid, 0, tdt)
+    fd, td, dv = framed(dout, 1, tdt)
+    dws = [torch.full((k, 512), -7.0, device='cuda') for k in ks]
+    dbs = [torch.full((k,), -7.0, device='cuda') for k in ks]
+    sc = torch.empty(L.dbx_head2_wgrad_scratch_bytes(nh, n * h), dtype=torch.uint8, device='cuda')
+    check(L.dbx_head2_wgrad(dt, C.byref(dv), C.byref(hv), (C.c_int32 * nh)(*ks), nh, (C.c_void_p * nh)(*[t.data_ptr() for t in dws]),
+                            (C.c_void_p * nh)(*[t.data_ptr() for t in dbs]), ptr(sc), stream_ptr()))
+    hr, dr = hid.to(tdt).double(), dout.to(tdt).double()
+    for i, k in enumerate(ks):
+        ref_w = torch.einsum('nkhw,nchw->kc', dr[:, slot * i:slot * i + k], hr[:, 512 * i:512 * (i + 1)])
+        ref_b = dr[:, slot * i:slot * i + k].sum(dim=(0, 2, 3))
+        scale = ref_w.abs().max().item()
+        assert (dws[i].double() - ref_w).abs().max().item() <= 2e-5 * scale + 1e-5
+        assert (dbs[i].double() - ref_b).abs().max().item() <= 1e-4
+    # repeatable bit for bit
+    dw0 = [t.clone() for t in dws]
+    check(L.dbx_head2_wgrad(dt, C.byref(dv), C.byref(hv), (C.c_int32 * nh)(*ks), nh, (C.c_void_p * nh)(*[t.data_ptr() for t in dws]),
+                            (C.c_void_p * nh)(*[t.data_ptr() for t in dbs]), ptr(sc), stream_ptr()))
+    assert all(torch.equal(a, b) for a, b in zip(dw0, dws))
