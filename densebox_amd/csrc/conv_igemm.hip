@@ -625,6 +625,157 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ v4: 64 -> 64 channels, 3x3
+// conv1_2 (forward and dgrad) at 240x240: N = 64 couts is too narrow for the band kernel -- every 512-pixel tile re-stages
+// its A band six times (3 ky x 2 K chunks) plus the weights: 270 KB of LDS fill per 512 pixels, fill-bound at 540 TFLOP/s.
+// Here the weights of ALL nine taps (64 x 576 x 2 B = 72 KB) are loaded into LDS ONCE per persistent workgroup and the
+// input is staged as 2-D halo tiles: an 8 x 32 pixel output tile needs 10 x 34 pixels x 128 B = 43.5 KB, read once for all
+// taps and the whole K -- 87 KB per 512 pixels.  Two halo buffers: the next tile's LDS-DMA loads run during the whole
+// compute of the current one; ONE barrier per tile, none inside its 18 K steps.  Wave w owns tile row w: 32 pixels x 64
+// couts, 2 x 4 accumulator fragments, 144 MFMAs per tile.  LDS: 64 x 1168 B weights (rows padded by 16 B: conflict-free
+// b128 column reads) + 2 x 43 520 B.  (Four fat waves on 32x32x16 MFMAs -- 1.5x fewer LDS fragment bytes -- measured 40 % slower.)
+struct C64Geo { int tiles_x, tiles_y, ntiles, H, W; };
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, const C64Geo tg) {
+    static_assert(sizeof(T) == 2, "16-bit types");
+    constexpr int TR = 8, TC = 32, HR = TR + 2, HC = TC + 2, HPX = HR * HC;      // 340 halo pixels of 128 B
+    constexpr int WROW = 1152 + 16, W_BYTES = 64 * WROW, IN_BYTES = HPX * 128;
+    constexpr int PIECES = (HPX + 7) / 8;                                         // 1-KiB pieces (8 pixels): 43
+    constexpr int NP = (PIECES + 7) / 8;                                          // per-wave slots: 6
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ws = smem;
+    char* In = smem + W_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- weights: packed rows [cout][tap][cin] of 1152 B -> LDS rows of 1168 B (register-staged, once per workgroup)
+    for (int c = tid; c < 64 * 72; c += 512) {
+        const int row = c / 72, ch = c - row * 72;
+        *(u32x4*)(Ws + row * WROW + ch * 16) = *(const u32x4*)(a.w + (size_t)row * a.ktot_bytes + ch * 16);
+    }
+    __syncthreads();
+
+    // ---- halo-tile loads: piece = 8 consecutive halo pixels (lane: pixel l>>3, chunk l&7), swizzle on the source chunk
+    const int lp = lane >> 3, lc = lane & 7;
+    const int pix_bytes = a.x_ld * 2;
+    int hr_[NP], hc_[NP];
+    bool pv[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int piece = wave + 8 * i;
+        const int p = piece * 8 + lp;                                             // halo pixel index
+        pv[i] = piece < PIECES;                                                   // (the last piece's pixels 340..343 land in slack)
+        const int pc = p < HPX ? p : HPX - 1;
+        hr_[i] = pc / HC; hc_[i] = pc - hr_[i] * HC;
+    }
+    auto issue = [&](int tile, int buf) {
+        const int n = tile / (tg.tiles_x * tg.tiles_y), r = tile - n * (tg.tiles_x * tg.tiles_y);
+        const int ty = r / tg.tiles_x, tx = r - ty * tg.tiles_x;
+        const int y0 = ty * TR, x0 = tx * TC;                                     // output origin == frame origin of the halo tile
+        char* dst = In + buf * (IN_BYTES + 1024);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (pv[i]) {
+                int fy = y0 + hr_[i]; fy = fy < a.x_hp ? fy : a.x_hp - 1;
+                const int p = (wave + 8 * i) * 8 + lp;
+                const char* src = a.x + ((size_t)(n * a.x_hp + fy) * a.x_wp + (x0 + hc_[i])) * pix_bytes + ((lc ^ dma_swz<128>(p)) << 4);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(dst + (wave + 8 * i) * 1024), 16, 0, 0);
+            }
+        }
+    };
+
+    // ---- fragment read offsets (tile-independent).  Pixels: halo pixel p = (wave + ky) * 34 + mi * 16 + fr + kx, chunk kc*4+g.
+    const int fr = lane & 15, g = lane >> 4;
+    int offX[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int p = (wave + t / 3) * HC + mi * 16 + fr + (t % 3);
+            offX[t][mi] = p * 128 + ((g ^ dma_swz<128>(p)) << 4);
+        }
+    const int offW = fr * WROW + g * 16;
+
+    const int first = blockIdx.x, stride = gridDim.x;
+    if (first >= tg.ntiles) return;
+    issue(first, 0);
+    const int cb = (lane >> 4) * 4;
+    const int epi = a.epi;
+    f32x4 bias[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bias[ni] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cb + ni * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    for (int tile = first; tile < tg.ntiles; tile += stride, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this tile's halo (issued one tile ago) + older stores
+        __builtin_amdgcn_s_barrier();                                             // everyone's pieces landed; everyone left the other buffer
+        if (tile + stride < tg.ntiles) issue(tile + stride, buf ^ 1);
+        const char* Xb = In + buf * (IN_BYTES + 1024);
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // 18 K steps (tap, 32-channel half), software-pipelined: the six fragments of step s+1 are read while the eight
+        // MFMAs of step s run; sched_group_barrier pins the interleave (2 MFMA : 2, 2, 1, 1 reads).
+        u32x4 wf[2][4], xf[2][2];
+        auto rd = [&](int st, u32x4 (&w)[4], u32x4 (&x)[2]) {
+            const int t = st >> 1, kc = st & 1;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) w[ni] = *(const u32x4*)(Ws + offW + ni * 16 * WROW + t * 128 + kc * 64);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) x[mi] = *(const u32x4*)(Xb + (offX[t][mi] ^ (kc << 6)));
+        };
+        rd(0, wf[0], xf[0]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st < 17) rd(st + 1, wf[(st + 1) & 1], xf[(st + 1) & 1]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) Mma<T>::run(wf[st & 1][ni], xf[st & 1][mi], acc[ni][mi]);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (st < 17) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (st < 17) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (st < 17) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (st < 17) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        // ---- epilogue: wave's tile row, pixel x0 + mi*16 + fr; lane holds couts cb + ni*16 + {0..3}
+        const int n = tile / (tg.tiles_x * tg.tiles_y), r = tile - n * (tg.tiles_x * tg.tiles_y);
+        const int ty = r / tg.tiles_x, tx = r - ty * tg.tiles_x;
+        const int oy = ty * TR + wave;
+        if (oy < tg.H) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int ox = tx * TC + mi * 16 + fr;
+                if (ox >= tg.W) continue;
+                T* yrow = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld + cb;
+                const T* grow = (const T*)a.gate + (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld + cb;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    f32x4 v = acc[ni][mi] + bias[ni];
+                    if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (epi & DBX_EPI_GATE) {
+                        const T* gt = grow + ni * 16;
+                        v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
+                        v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
+                    }
+                    T* o = yrow + ni * 16;
+                    if (epi & DBX_EPI_ACCUM) { v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]); }
+                    T pk[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+                    *(u32x2*)o = *(const u32x2*)pk;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static int64_t packed_k_elems(const dbx_conv_desc* d) {
     const int es = dbx_esize(d->dtype);
@@ -683,6 +834,31 @@ static int launch_conv_band(const ConvArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((conv3x3_band_kernel<T, BM, BN, STAGES, WM, WN>), dim3(a.nblocks), dim3(512), smem, s, a);
     DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+template <typename T>
+static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        constexpr int smem = 64 * 1168 + 2 * (340 * 128 + 1024);
+        static_assert(smem <= 160 * 1024, "LDS budget");
+        static bool attr_set = false;
+        if (!attr_set) {
+            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            DBX_HIP(hipGetDevice(&dev));
+            DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        C64Geo tg;
+        tg.tiles_x = (w + 31) / 32; tg.tiles_y = (h + 7) / 8; tg.ntiles = n * tg.tiles_x * tg.tiles_y; tg.H = h; tg.W = w;
+        const int grid = tg.ntiles < ncu ? tg.ntiles : ncu;                 // one persistent workgroup per CU
+        hipLaunchKernelGGL((conv3x3_c64_kernel<T>), dim3(grid), dim3(512), smem, s, a, tg);
+        DBX_LAUNCH_CHECK();
+    }
     return DBX_OK;
 }
 
@@ -766,6 +942,10 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             a.nblocks = tiles256 * a.ntile_n;
             return launch_conv_band<T, 256, 128, 3, 4, 2>(a, s);
         }
+        // 64 -> 64 channels on big maps: weights-stationary halo-tile kernel (DBX_CONV_VARIANT=4 keeps the band kernel)
+        if (d->cin_pad == 64 && d->cout_pad == 64 && y->c == 64 && x->c >= 64 && a.ktot_bytes == 1152 && conv_variant() != 4 &&
+            (long long)x->n * ((x->h + 7) / 8) * ((x->w + 31) / 32) >= 256)             // at least one 8x32 tile per CU
+            return launch_conv_c64<T>(a, x->n, x->h, x->w, s);
         a.ntile_n = y->c / 64;
         if (tall) { a.nblocks = tiles512 * a.ntile_n; return launch_conv_band<T, 512, 64, 3, 8, 1>(a, s); }
         a.nblocks = tiles256 * a.ntile_n;

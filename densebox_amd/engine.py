@@ -322,6 +322,8 @@ class Engine:
                 bn = 256 if (y.c % 256 == 0 and cout_pad % 256 == 0) else (128 if (y.c % 128 == 0 and cout_pad % 128 == 0) else 64)
                 tall = bn < 256 and (x.n * (x.h + 2) * (x.w + 2) + 511) // 512 >= 1024
                 name = 'conv3x3_band_kernel<%s,%d,%d>' % (tn, 512 if tall else 256, bn)
+                if bn == 64 and cin_pad == 64 and cout_pad == 64 and x.n * ((x.h + 7) // 8) * ((x.w + 31) // 32) >= 256:
+                    name = 'conv3x3_c64_kernel<%s>' % tn
             else:
                 wide = (not narrow) and cout_pad % 256 == 0 and y.c % 256 == 0
                 name = 'conv_igemm_dma_kernel<%s,%s>' % (tn, '256,64' if narrow else ('256,256' if wide else '256,128'))

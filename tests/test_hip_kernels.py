@@ -38,6 +38,7 @@ def pack(L, dt, w, cin_pad, cout_pad, mode=0):
 CONV_CASES = [  # n, h, w, cin, cout, k, pad
     (2, 20, 28, 64, 64, 3, 1), (3, 17, 23, 128, 256, 3, 1), (1, 30, 30, 512, 512, 3, 1), (2, 15, 15, 768, 1024, 1, 0),
     (2, 14, 14, 64, 64, 5, 0), (1, 33, 9, 256, 128, 3, 1),
+    (10, 53, 100, 64, 64, 3, 1),      # ragged 8x32 tiles of the weights-stationary 64->64 kernel
 ]
 
 
