@@ -776,6 +776,97 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------ v5: 3 (8) -> 64 channels, 3x3
+// conv1_1 forward: 26 FLOP per byte, bound by writing its 64-channel output (472 MB at batch 64).  Same 8 x 32 halo tiles
+// as v4 with one 16-byte chunk per pixel (5.4 KB per tile); a K step of 32 elements covers four taps, so a lane's B
+// fragment is the pixel shifted by ITS tap (three K steps for nine taps; taps 9..11 have zero weights and re-read tap 8).
+// The wave's weight fragments (4 x 3) live in registers for the whole kernel; two workgroups per CU.
+template <typename T>
+__global__ __launch_bounds__(512, 2) void conv3x3_c8_kernel(const ConvArgs a, const C64Geo tg) {
+    static_assert(sizeof(T) == 2, "16-bit types");
+    constexpr int TR = 8, TC = 32, HR = TR + 2, HC = TC + 2, HPX = HR * HC;      // 340 halo pixels of 16 B
+    constexpr int IN_BYTES = 6 * 1024;                                            // six 1-KiB pieces (64 pixels each)
+    __shared__ __attribute__((aligned(16))) char In[2 * IN_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, g = lane >> 4;
+    const int pix_bytes = a.x_ld * 2;
+
+    u32x4 wf[3][4];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) wf[ks][ni] = *(const u32x4*)(a.w + (size_t)(ni * 16 + fr) * a.ktot_bytes + (ks * 4 + g) * 16);
+    // halo pixel of (tile row `wave`, pixel block mi, lane's tap of K step ks)
+    int offX[3][2];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        int tap = ks * 4 + g; tap = tap < 9 ? tap : 8;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) offX[ks][mi] = ((wave + tap / 3) * HC + mi * 16 + fr + tap % 3) * 16;
+    }
+    auto issue = [&](int tile, int buf) {
+        if (wave < 6) {
+            const int n = tile / (tg.tiles_x * tg.tiles_y), r = tile - n * (tg.tiles_x * tg.tiles_y);
+            const int ty = r / tg.tiles_x, tx = r - ty * tg.tiles_x;
+            const int p = wave * 64 + lane, pc = p < HPX ? p : HPX - 1;
+            const int hr = pc / HC, hc = pc - hr * HC;
+            int fy = ty * TR + hr; fy = fy < a.x_hp ? fy : a.x_hp - 1;
+            const char* src = a.x + ((size_t)(n * a.x_hp + fy) * a.x_wp + (tx * TC + hc)) * pix_bytes;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(In + buf * IN_BYTES + wave * 1024), 16, 0, 0);
+        }
+    };
+    const int first = blockIdx.x, stride = gridDim.x;
+    if (first >= tg.ntiles) return;
+    issue(first, 0);
+    const int cb = g * 4;
+    const int epi = a.epi;
+    f32x4 bias[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) bias[ni] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cb + ni * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    int buf = 0;
+    for (int tile = first; tile < tg.ntiles; tile += stride, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tile + stride < tg.ntiles) issue(tile + stride, buf ^ 1);
+        const char* Xb = In + buf * IN_BYTES;
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            u32x4 xf[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) xf[mi] = *(const u32x4*)(Xb + offX[ks][mi]);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) Mma<T>::run(wf[ks][ni], xf[mi], acc[ni][mi]);
+        }
+        const int n = tile / (tg.tiles_x * tg.tiles_y), r = tile - n * (tg.tiles_x * tg.tiles_y);
+        const int ty = r / tg.tiles_x, tx = r - ty * tg.tiles_x;
+        const int oy = ty * TR + wave;
+        if (oy < tg.H) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int ox = tx * TC + mi * 16 + fr;
+                if (ox >= tg.W) continue;
+                T* yrow = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld + cb;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    f32x4 v = acc[ni][mi] + bias[ni];
+                    if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    T pk[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
+                    *(u32x2*)(yrow + ni * 16) = *(const u32x2*)pk;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static int64_t packed_k_elems(const dbx_conv_desc* d) {
     const int es = dbx_esize(d->dtype);
@@ -834,6 +925,24 @@ static int launch_conv_band(const ConvArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((conv3x3_band_kernel<T, BM, BN, STAGES, WM, WN>), dim3(a.nblocks), dim3(512), smem, s, a);
     DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+template <typename T>
+static int launch_conv_c8(const ConvArgs& a, int n, int h, int w, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            DBX_HIP(hipGetDevice(&dev));
+            DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        C64Geo tg;
+        tg.tiles_x = (w + 31) / 32; tg.tiles_y = (h + 7) / 8; tg.ntiles = n * tg.tiles_x * tg.tiles_y; tg.H = h; tg.W = w;
+        const int grid = tg.ntiles < 2 * ncu ? tg.ntiles : 2 * ncu;         // two persistent workgroups per CU
+        hipLaunchKernelGGL((conv3x3_c8_kernel<T>), dim3(grid), dim3(512), 0, s, a, tg);
+        DBX_LAUNCH_CHECK();
+    }
     return DBX_OK;
 }
 
@@ -973,6 +1082,11 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
         return launch_conv_dma<T, 256, 128, 128, 3, 4, 2>(a, s);
     }
+    // conv1_1: one chunk per pixel, 64 couts, plain bias/ReLU epilogue, big maps: halo-tile kernel
+    if (smallc && sizeof(T) == 2 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 && d->cout_pad == 64 && y->c == 64 &&
+        x->ld * ES == 16 && !(d->epilogue & ~(DBX_EPI_BIAS | DBX_EPI_RELU)) && a.ktot_bytes == 256 && conv_variant() == 0 &&
+        (long long)x->n * ((x->h + 7) / 8) * ((x->w + 31) / 32) >= 256)
+        return launch_conv_c8<T>(a, x->n, x->h, x->w, s);
     // tile choice: couts are tiled by 128 unless the layer has 64 (or the result is tiny, e.g. the 512->k heads)
     const bool narrow = (d->cout_pad % 128 != 0) || y->c <= 64;
     if (narrow) {
