@@ -78,6 +78,21 @@ template <> struct Mma<float> {
     }
 };
 
+// Epilogue store helper (16-bit types): fragments ni and ni+1 of one pixel (lane (fr, g) holds couts 4g..4g+3 of each) are
+// packed and exchanged across the 16-lane rows with v_permlane16_swap so that every lane owns EIGHT consecutive couts:
+// rows g = 0, 2 end up with fragment ni, rows 1, 3 with fragment ni+1, couts (g>>1)*8 .. +7.  One 16-byte store per lane
+// then writes 64 contiguous bytes per pixel instead of two 8-byte stores writing 32.  Must be called by all 64 lanes.
+template <typename T>
+__device__ __forceinline__ u32x4 pair_exchange(const f32x4& va, const f32x4& vb) {
+    T pa[4] = {from_f32<T>(va.x), from_f32<T>(va.y), from_f32<T>(va.z), from_f32<T>(va.w)};
+    T pb[4] = {from_f32<T>(vb.x), from_f32<T>(vb.y), from_f32<T>(vb.z), from_f32<T>(vb.w)};
+    const u32x2 A = *(const u32x2*)pa, B = *(const u32x2*)pb;
+    const auto r0 = __builtin_amdgcn_permlane16_swap(A.x, B.x, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(A.y, B.y, false, false);
+    return (u32x4){r0[0], r1[0], r0[1], r1[1]};
+}
+__device__ __forceinline__ int pair_cout_off(int g, int ni) { return (ni + (g & 1)) * 16 + (g >> 1) * 8; }   // elements, ni even
+
 // HOIST: fetch the bias fragments once up front (a win for the one-tile-per-workgroup v1 kernel; in the persistent DMA
 // kernel the early loads make the compiler drain vmcnt in front of the next tile's LDS-DMA issue, so it stays per-fragment).
 template <typename T, int MI, int NI, bool HOIST = false>
@@ -750,26 +765,32 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, cons
         const int n = tile / (tg.tiles_x * tg.tiles_y), r = tile - n * (tg.tiles_x * tg.tiles_y);
         const int ty = r / tg.tiles_x, tx = r - ty * tg.tiles_x;
         const int oy = ty * TR + wave;
-        if (oy < tg.H) {
+        if (oy < tg.H) {                                                         // wave-uniform
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int ox = tx * TC + mi * 16 + fr;
-                if (ox >= tg.W) continue;
-                T* yrow = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld + cb;
+                const bool ok = ox < tg.W;
+                T* ypix = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
                 const T* grow = (const T*)a.gate + (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld + cb;
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
+                auto fin = [&](int ni) {
                     f32x4 v = acc[ni][mi] + bias[ni];
                     if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (epi & DBX_EPI_GATE) {
+                    if ((epi & DBX_EPI_GATE) && ok) {
                         const T* gt = grow + ni * 16;
                         v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
                         v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
                     }
-                    T* o = yrow + ni * 16;
-                    if (epi & DBX_EPI_ACCUM) { v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]); }
-                    T pk[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
-                    *(u32x2*)o = *(const u32x2*)pk;
+                    if ((epi & DBX_EPI_ACCUM) && ok) {
+                        const T* o = ypix + cb + ni * 16;
+                        v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]);
+                    }
+                    return v;
+                };
+#pragma unroll
+                for (int ni = 0; ni < 4; ni += 2) {
+                    const f32x4 v0 = fin(ni), v1 = fin(ni + 1);
+                    const u32x4 o = pair_exchange<T>(v0, v1);                     // all lanes
+                    if (ok) *(u32x4*)(ypix + pair_cout_off(g, ni)) = o;
                 }
             }
         }
@@ -849,18 +870,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c8_kernel(const ConvArgs a, co
         const int n = tile / (tg.tiles_x * tg.tiles_y), r = tile - n * (tg.tiles_x * tg.tiles_y);
         const int ty = r / tg.tiles_x, tx = r - ty * tg.tiles_x;
         const int oy = ty * TR + wave;
-        if (oy < tg.H) {
+        if (oy < tg.H) {                                                         // wave-uniform
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
                 const int ox = tx * TC + mi * 16 + fr;
-                if (ox >= tg.W) continue;
-                T* yrow = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld + cb;
+                T* ypix = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    f32x4 v = acc[ni][mi] + bias[ni];
-                    if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    T pk[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
-                    *(u32x2*)(yrow + ni * 16) = *(const u32x2*)pk;
+                for (int ni = 0; ni < 4; ni += 2) {
+                    f32x4 v0 = acc[ni][mi] + bias[ni], v1 = acc[ni + 1][mi] + bias[ni + 1];
+                    if (epi & DBX_EPI_RELU) {
+                        v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                        v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+                    }
+                    const u32x4 o = pair_exchange<T>(v0, v1);                     // all lanes
+                    if (ox < tg.W) *(u32x4*)(ypix + pair_cout_off(g, ni)) = o;
                 }
             }
         }
