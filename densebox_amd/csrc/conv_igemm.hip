@@ -118,6 +118,63 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NI
     int oy = r / a.Wo, ox = r - oy * a.Wo;
     const int Ho = a.HoWo / a.Wo;
     const bool stepwise = a.Wo >= 16;                       // one row wrap at most per 16-pixel advance
+    if constexpr (sizeof(T) == 2 && NI % 2 == 0) {
+        // framed 16-bit output with every fragment of this wave inside the valid couts (uniform): fragment pairs are
+        // exchanged across the 16-lane rows and leave as 16-byte stores of eight consecutive couts (see pair_exchange)
+        if (!(epi & DBX_EPI_F32_NCHW) && n0 + wn_off + NI * 16 <= cvalid) {
+            const int g4 = lane >> 4;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = mb + mi * 16;
+                if (mi > 0) {
+                    if (stepwise) {
+                        ox += 16;
+                        if (ox >= a.Wo) { ox -= a.Wo; if (++oy == Ho) { oy = 0; ++n; } }
+                    } else {
+                        n = m / a.HoWo; const int rr = m - n * a.HoWo;
+                        oy = rr / a.Wo; ox = rr - oy * a.Wo;
+                    }
+                }
+                const bool ok = m < a.M;                     // per pixel: the four rows of a pixel agree
+                T* ypix = (T*)ybase + ((size_t)(n * y_hp + oy + y_pad) * y_wp + (ox + y_pad)) * (size_t)y_ld + (n0 + wn_off - cshift);
+                const size_t gpix = ((size_t)(n * g_hp + oy + g_pad) * g_wp + (ox + g_pad)) * (size_t)g_ld;
+                auto fin = [&](int ni) {
+                    const int c = cb + ni * 16;
+                    f32x4 v = acc[ni][mi];
+                    if constexpr (HOIST) v += hbias[ni];
+                    else if (epi & DBX_EPI_BIAS) v += *(const f32x4*)(a.bias + c);
+                    if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if ((epi & DBX_EPI_GATE) && ok) {
+                        const T* gt = (const T*)gbase + gpix + (c - cshift);
+                        v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
+                        v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
+                    }
+                    if ((epi & DBX_EPI_DROPMASK) && ok) {
+                        const unsigned int mk = *(const unsigned int*)(a.dropmask + (size_t)m * a.dm_ld + c);
+                        v.x = (mk & 0xffu) ? v.x * 2.f : 0.f; v.y = (mk & 0xff00u) ? v.y * 2.f : 0.f;
+                        v.z = (mk & 0xff0000u) ? v.z * 2.f : 0.f; v.w = (mk & 0xff000000u) ? v.w * 2.f : 0.f;
+                    }
+                    if (epi & DBX_EPI_DROPHASH) {
+                        const unsigned kb = dbx_drop_bits4(a.drop_seed, (unsigned)m, (unsigned)c >> 2);
+                        v.x = (kb & 1u) ? v.x * 2.f : 0.f; v.y = (kb & 2u) ? v.y * 2.f : 0.f;
+                        v.z = (kb & 4u) ? v.z * 2.f : 0.f; v.w = (kb & 8u) ? v.w * 2.f : 0.f;
+                    }
+                    if ((epi & DBX_EPI_ACCUM) && ok) {
+                        const T* o = ypix + g4 * 4 + ni * 16;
+                        v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]);
+                    }
+                    return v;
+                };
+#pragma unroll
+                for (int ni = 0; ni < NI; ni += 2) {
+                    const f32x4 v0 = fin(ni), v1 = fin(ni + 1);
+                    const u32x4 o = pair_exchange<T>(v0, v1);             // all lanes
+                    if (ok) *(u32x4*)(ypix + pair_cout_off(g4, ni)) = o;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int m = mb + mi * 16;
@@ -602,30 +659,41 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
         const int rem = (int)(q - (long long)n * fpix);
         fy = rem / a.x_wp; fx = rem - fy * a.x_wp;
     }
+    static_assert(NI % 2 == 0, "fragment pairs");
+    const int g4 = lane >> 4;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
-        if (n < nimg && fy >= 1 && fy <= a.x_hp - 2 && fx >= 1 && fx <= a.x_wp - 2) {
-            const int oy = fy - 1, ox = fx - 1;
-            T* yrow = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld + cb;
-            const T* grow = (const T*)a.gate + (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld + cb;
+        // interior test per pixel (= per fr): the four rows g of a pixel agree, so the row exchange below is safe
+        const bool ok = n < nimg && fy >= 1 && fy <= a.x_hp - 2 && fx >= 1 && fx <= a.x_wp - 2;
+        const int oy = fy - 1, ox = fx - 1;
+        T* ypix = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld + n0 + wn * WTN;
+        const T* grow = (const T*)a.gate + (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld + cb;
+        auto fin = [&](int ni) {
+            f32x4 v = acc[ni][mi] + bias[ni];
+            if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if ((epi & DBX_EPI_GATE) && ok) {
+                const T* gt = grow + ni * 16;
+                v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
+                v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
+            }
+            if ((epi & DBX_EPI_ACCUM) && ok) {
+                const T* o = ypix + g4 * 4 + ni * 16;
+                v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]);
+            }
+            return v;
+        };
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ni += 2) {
+                const f32x4 v0 = fin(ni), v1 = fin(ni + 1);
+                const u32x4 o = pair_exchange<T>(v0, v1);                          // all lanes
+                if (ok && cb + ni * 16 < a.cout_valid) *(u32x4*)(ypix + pair_cout_off(g4, ni)) = o;
+            }
+        } else {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                if (cb + ni * 16 >= a.cout_valid) continue;
-                f32x4 v = acc[ni][mi] + bias[ni];
-                if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (epi & DBX_EPI_GATE) {
-                    const T* gt = grow + ni * 16;
-                    v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
-                    v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
-                }
-                T* o = yrow + ni * 16;
-                if (epi & DBX_EPI_ACCUM) { v.x += to_f32(o[0]); v.y += to_f32(o[1]); v.z += to_f32(o[2]); v.w += to_f32(o[3]); }
-                if constexpr (sizeof(T) == 2) {
-                    T pk[4] = {from_f32<T>(v.x), from_f32<T>(v.y), from_f32<T>(v.z), from_f32<T>(v.w)};
-                    *(u32x2*)o = *(const u32x2*)pk;
-                } else {
-                    *(f32x4*)o = v;
-                }
+                const f32x4 v = fin(ni);
+                if (ok && cb + ni * 16 < a.cout_valid) *(f32x4*)(ypix + g4 * 4 + ni * 16) = v;
             }
         }
         if (a.x_wp >= 16) {                                  // one row wrap at most per 16-pixel advance
