@@ -333,9 +333,9 @@ __global__ __launch_bounds__(512) void wgrad_wide_kernel(const WgradArgs a) {
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 if constexpr (DType<T>::id == DBX_F16)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[kk][mi]), __builtin_bit_cast(f16x8, bf[grp & 1]), acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bf[grp & 1]), __builtin_bit_cast(f16x8, af[kk][mi]), acc[mi][ni], 0, 0, 0);
                 else
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kk][mi]), __builtin_bit_cast(bf16x8, bf[grp & 1]), acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[grp & 1]), __builtin_bit_cast(bf16x8, af[kk][mi]), acc[mi][ni], 0, 0, 0);
             }
             if (grp < 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
             else if (grp < 15) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -346,17 +346,14 @@ __global__ __launch_bounds__(512) void wgrad_wide_kernel(const WgradArgs a) {
     }
     {
         float* P = a.partial + (((long long)split * a.co_pad) * a.taps) * a.ci_pad;
-        const int co_b = tile_co * 256 + wm * 64 + (lane >> 4) * 4;
-        const int ci_b = tile_ci * 256 + wn * 128 + (lane & 15);
+        // x is the first MFMA operand: a lane holds four consecutive ci of one co -> one 16-byte store per fragment
+        const int co_b = tile_co * 256 + wm * 64 + (lane & 15);
+        const int ci_b = tile_ci * 256 + wn * 128 + (lane >> 4) * 4;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 8; ++ni) {
-                const float v[4] = {acc[mi][ni].x, acc[mi][ni].y, acc[mi][ni].z, acc[mi][ni].w};
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    P[((long long)(co_b + mi * 16 + r) * a.taps + tap) * a.ci_pad + ci_b + ni * 16] = v[r];
-            }
+            for (int ni = 0; ni < 8; ++ni)
+                *(f32x4*)(P + ((long long)(co_b + mi * 16) * a.taps + tap) * a.ci_pad + ci_b + ni * 16) = acc[mi][ni];
     }
     if (do_bias) {
         __syncthreads();
@@ -488,9 +485,9 @@ __global__ __launch_bounds__(512) void wgrad_row3_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     if constexpr (DType<T>::id == DBX_F16)
-                        acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[kk][mi]), __builtin_bit_cast(f16x8, bf[kx]), acc[kx][mi][ni], 0, 0, 0);
+                        acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bf[kx]), __builtin_bit_cast(f16x8, af[kk][mi]), acc[kx][mi][ni], 0, 0, 0);
                     else
-                        acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[kk][mi]), __builtin_bit_cast(bf16x8, bf[kx]), acc[kx][mi][ni], 0, 0, 0);
+                        acc[kx][mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[kx]), __builtin_bit_cast(bf16x8, af[kk][mi]), acc[kx][mi][ni], 0, 0, 0);
                 }
                 if (u < 2 && kx == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);          // 3 run reads + 4 dz reads
                 else if (u < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -503,19 +500,16 @@ __global__ __launch_bounds__(512) void wgrad_row3_kernel(const WgradArgs a) {
     }
     {
         float* P = a.partial + (((long long)split * a.co_pad) * 9) * a.ci_pad;
-        const int co_b = tile_co * 128 + wm * 64 + (lane >> 4) * 4;
-        const int ci_b = tile_ci * 128 + wn * 32 + (lane & 15);
+        // x is the first MFMA operand: a lane holds four consecutive ci of one co -> one 16-byte store per fragment
+        const int co_b = tile_co * 128 + wm * 64 + (lane & 15);
+        const int ci_b = tile_ci * 128 + wn * 32 + (lane >> 4) * 4;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const float v[4] = {acc[kx][mi][ni].x, acc[kx][mi][ni].y, acc[kx][mi][ni].z, acc[kx][mi][ni].w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        P[((long long)(co_b + mi * 16 + r) * 9 + ky * 3 + kx) * a.ci_pad + ci_b + ni * 16] = v[r];
-                }
+                for (int ni = 0; ni < 2; ++ni)
+                    *(f32x4*)(P + ((long long)(co_b + mi * 16) * 9 + ky * 3 + kx) * a.ci_pad + ci_b + ni * 16) = acc[kx][mi][ni];
     }
     if (do_bias) {
         __syncthreads();
@@ -662,9 +656,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
                 for (int mi = 0; mi < 2; ++mi) {
                     f32x4& cc = acc[ky * 3 + kx][mi][ni];
                     if constexpr (DType<T>::id == DBX_F16)
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, af[mi]), __builtin_bit_cast(f16x8, bf[kx]), cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bf[kx]), __builtin_bit_cast(f16x8, af[mi]), cc, 0, 0, 0);
                     else
-                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[mi]), __builtin_bit_cast(bf16x8, bf[kx]), cc, 0, 0, 0);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[kx]), __builtin_bit_cast(bf16x8, af[mi]), cc, 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
                 if (u < 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -676,18 +670,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
 
     {
         float* P = a.partial + (((long long)split * a.co_pad) * 9) * a.ci_pad;
-        const int co_b = tile_co * 64 + wm * 32 + (lane >> 4) * 4;
-        const int ci_b = tile_ci * 64 + wn * 32 + (lane & 15);
+        // x is the first MFMA operand: a lane holds four consecutive ci of one co -> one 16-byte store per fragment
+        const int co_b = tile_co * 64 + wm * 32 + (lane & 15);
+        const int ci_b = tile_ci * 64 + wn * 32 + (lane >> 4) * 4;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const float v[4] = {acc[t][mi][ni].x, acc[t][mi][ni].y, acc[t][mi][ni].z, acc[t][mi][ni].w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) P[((long long)(co_b + mi * 16 + r) * 9 + t) * a.ci_pad + ci_b + ni * 16] = v[r];
-                }
+                for (int ni = 0; ni < 2; ++ni)
+                    *(f32x4*)(P + ((long long)(co_b + mi * 16) * 9 + t) * a.ci_pad + ci_b + ni * 16) = acc[t][mi][ni];
     }
     if (do_bias) {
         __syncthreads();
