@@ -92,6 +92,17 @@ __device__ __forceinline__ u32x4 pair_exchange(const f32x4& va, const f32x4& vb)
     return (u32x4){r0[0], r1[0], r0[1], r1[1]};
 }
 __device__ __forceinline__ int pair_cout_off(int g, int ni) { return (ni + (g & 1)) * 16 + (g >> 1) * 8; }   // elements, ni even
+// ReLU gate on the exchanged layout: keep an output where the 16-bit gate value is positive (one 16-byte gate load per lane).
+__device__ __forceinline__ u32x4 gate_packed16(const u32x4& v, const u32x4& g) {
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo = ((g[i] & 0xffffu) - 1u) < 0x7fffu ? 0x0000ffffu : 0u;     // 0x0001..0x7fff: positive, non-zero
+        const unsigned hi = ((g[i] >> 16) - 1u) < 0x7fffu ? 0xffff0000u : 0u;
+        o[i] = v[i] & (lo | hi);
+    }
+    return o;
+}
 
 // HOIST: fetch the bias fragments once up front (a win for the one-tile-per-workgroup v1 kernel; in the persistent DMA
 // kernel the early loads make the compiler drain vmcnt in front of the next tile's LDS-DMA issue, so it stays per-fragment).
@@ -671,10 +682,12 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
         auto fin = [&](int ni) {
             f32x4 v = acc[ni][mi] + bias[ni];
             if (epi & DBX_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if ((epi & DBX_EPI_GATE) && ok) {
-                const T* gt = grow + ni * 16;
-                v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
-                v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
+            if constexpr (sizeof(T) == 4) {
+                if ((epi & DBX_EPI_GATE) && ok) {
+                    const T* gt = grow + ni * 16;
+                    v.x = to_f32(gt[0]) > 0.f ? v.x : 0.f; v.y = to_f32(gt[1]) > 0.f ? v.y : 0.f;
+                    v.z = to_f32(gt[2]) > 0.f ? v.z : 0.f; v.w = to_f32(gt[3]) > 0.f ? v.w : 0.f;
+                }
             }
             if ((epi & DBX_EPI_ACCUM) && ok) {
                 const T* o = ypix + g4 * 4 + ni * 16;
@@ -686,8 +699,11 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
 #pragma unroll
             for (int ni = 0; ni < NI; ni += 2) {
                 const f32x4 v0 = fin(ni), v1 = fin(ni + 1);
-                const u32x4 o = pair_exchange<T>(v0, v1);                          // all lanes
-                if (ok && cb + ni * 16 < a.cout_valid) *(u32x4*)(ypix + pair_cout_off(g4, ni)) = o;
+                u32x4 o = pair_exchange<T>(v0, v1);                                // all lanes
+                if (ok && cb + ni * 16 < a.cout_valid) {
+                    if (epi & DBX_EPI_GATE) o = gate_packed16(o, *(const u32x4*)(grow - g4 * 4 + pair_cout_off(g4, ni)));
+                    *(u32x4*)(ypix + pair_cout_off(g4, ni)) = o;
+                }
             }
         } else {
 #pragma unroll
