@@ -5,6 +5,7 @@ torch is used for device memory, streams and autograd bookkeeping only; every FL
 network runs in the library.  Layer graph = DenseBox.py:180-228 / :412-473 / :674-738.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -550,10 +551,35 @@ class Engine:
                 return torch.zeros((n, k, h4, w4), dtype=torch.float32, device=dev)
             return g.to(torch.float32).contiguous()
 
+        # Weight gradients are off the critical path (only dz -> dgrad -> next dz is a chain): they go to a side stream so
+        # their workgroups fill the CUs that the data-gradient kernels' last rounds leave idle.  Every gradient producer and
+        # its sink.ready() (which may launch an all-reduce ordered after the CURRENT stream) run on that stream; the main
+        # stream joins it before backward_raw returns.  Off while profiling (per-kernel HIP-event times must not overlap).
+        main = torch.cuda.current_stream()
+        side = None
+        multi = sink is not None and getattr(sink, 'world', 1) > 1      # (collectives keep the single-stream ordering)
+        if self.profile is None and not multi and os.environ.get('DBX_SIDE_STREAM', '1') != '0':
+            if getattr(self, '_side', None) is None:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+
+        def on_side(fn):
+            if side is None:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                return fn()
+
         def conv_bwd(stem, dz, x, kh, kw, cpad, co, ci):
-            self._wgrad(dt, dz, x, kh, kw, cpad, co, ci, new_grad(stem + '.weight'), new_grad(stem + '.bias'))
-            if sink is not None:
-                sink.ready([stem + '.weight', stem + '.bias'])
+            dw, db = new_grad(stem + '.weight'), new_grad(stem + '.bias')
+
+            def run():
+                self._wgrad(dt, dz, x, kh, kw, cpad, co, ci, dw, db)
+                if sink is not None:
+                    sink.ready([stem + '.weight', stem + '.bias'])
+            on_side(run)
 
         def dgrad(stem, src, dst, kh, kw, cpad, rows_pad, cin_pad, gate=None, epi=0, dropmask=None):
             wp = self._w_bwd(dt, stem, rows_pad, cin_pad)
@@ -596,15 +622,17 @@ class Engine:
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        check(L.dbx_head2_wgrad(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_int32 * nh)(*[k for _, k in heads]), nh,
-                                (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
-                                ptr(self._h2_scratch), s))
+        def run_h2():
+            check(L.dbx_head2_wgrad(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_int32 * nh)(*[k for _, k in heads]), nh,
+                                    (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
+                                    ptr(self._h2_scratch), stream_ptr()))
+            if sink is not None:
+                sink.ready(['conv5_2_%s.weight' % st for st, _ in heads] + ['conv5_2_%s.bias' % st for st, _ in heads])
+        on_side(run_h2)
         if prof is not None:
             ev1.record()
             prof.append({'kernel': 'head2_wgrad_kernel<%s>' % ('f16', 'bf16', 'f32')[dt],
                          'flops': 2.0 * hv.n * hv.h * hv.w * 512 * sum(k for _, k in heads), 'start': ev0, 'end': ev1})
-        if sink is not None:
-            sink.ready(['conv5_2_%s.weight' % st for st, _ in heads] + ['conv5_2_%s.bias' % st for st, _ in heads])
         w2s = [self._param('conv5_2_%s.weight' % st).detach() for st, _ in heads]      # fp32 [k,512,1,1]
         check(L.dbx_head2_dgrad(dt, C.byref(B['d_out'].view()), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]),
                                 (C.c_int32 * nh)(*[k for _, k in heads]), nh, C.byref(B['d_hid'].view()),
@@ -617,12 +645,14 @@ class Engine:
         else:
             dw1 = torch.empty((512 * nh, 768, 1, 1), dtype=torch.float32, device=dev)
             db1 = torch.empty((512 * nh,), dtype=torch.float32, device=dev)
-        self._wgrad(dt, B['d_hid'].view(), B['fusion'].view(), 1, 1, 0, 512 * nh, 768, dw1, db1)
+        def run_h1():
+            self._wgrad(dt, B['d_hid'].view(), B['fusion'].view(), 1, 1, 0, 512 * nh, 768, dw1, db1)
+            if sink is not None:
+                sink.ready(w1n + b1n)
+        on_side(run_h1)
         for i, (stem, _) in enumerate(heads):
             G['conv5_1_%s.weight' % stem] = dw1[512 * i:512 * (i + 1)]
             G['conv5_1_%s.bias' % stem] = db1[512 * i:512 * (i + 1)]
-        if sink is not None:
-            sink.ready(w1n + b1n)
         w1t = self._w_heads1_bwd(dt)                          # [768 rows][512*nh]
         row_bytes = 512 * nh * _lib.ESIZE[dt]
         c34 = B['fusion'].view(512, 256)
@@ -676,4 +706,6 @@ class Engine:
             if dxn is not None:
                 dgrad(stem, B[dzn].view(), B[dxn].view(), 3, 3, 1, max(64, cin), cout,
                       gate=B[gaten].view() if gaten else None)
+        if side is not None:
+            main.wait_stream(side)
         return G
