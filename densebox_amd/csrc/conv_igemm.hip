@@ -1148,11 +1148,15 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         const long long Q = (long long)x->n * a.x_hp * a.x_wp;
         const int tiles256 = (int)((Q + 255) / 256), tiles512 = (int)((Q + 511) / 512);
         const bool tall = conv_variant() != 4 && tiles512 >= 1024;      // enough work for >= 4 tall tiles per CU
-        if (y->c % 256 == 0 && d->cout_pad % 256 == 0) {
+        // small problems (single-image inference: 64x64 or 128x128 maps): a wide tile would leave most CUs without a workgroup,
+        // so the N tile narrows until there are ~200 workgroups (the A band is then re-read by more N tiles, from L2)
+        const int want = 200;
+        const bool few256 = (long long)tiles256 * (y->c / 256) < want, few128 = (long long)tiles256 * (y->c / 128) < want;
+        if (y->c % 256 == 0 && d->cout_pad % 256 == 0 && !few256) {
             a.ntile_n = y->c / 256; a.nblocks = tiles256 * a.ntile_n;
             return launch_conv_band<T, 256, 256, 2, 2, 4>(a, s);
         }
-        if (y->c % 128 == 0 && d->cout_pad % 128 == 0) {
+        if (y->c % 128 == 0 && d->cout_pad % 128 == 0 && (!few128 || y->c == 128)) {
             a.ntile_n = y->c / 128;
             if (tall) { a.nblocks = tiles512 * a.ntile_n; return launch_conv_band<T, 512, 128, 2, 4, 2>(a, s); }
             a.nblocks = tiles256 * a.ntile_n;
