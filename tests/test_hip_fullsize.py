@@ -119,3 +119,26 @@ def test_full_image_decode_properties():
         os.environ.pop('DBX_GRAPH')
     d1, k1 = net.detect(img, K=10, nms_thresh=0.4)
     assert np.array_equal(d1, d2) and k1 == k2
+
+
+def test_batch64_f16_forward_plus_loss_two_head():
+    """configs[1]: batch 64, f16, score + bbox heads only, forward + fused loss.  The loss is a sum over patches with global
+    mining constants: four shards of 16 add up to the batch-64 value; the fp32 path agrees within the f16 map tolerance."""
+    from densebox_amd import labels as LB
+    n = 64
+    x, bbox, vert, lab = synth.synth_batch(n, seed=101, neg_frac=0.1)
+    x = x.cuda()
+    p_global = int(LB.positive_count(bbox, None).sum())
+    _, half = LB.neg_counts(p_global, n)
+    rs = np.random.RandomState(3)
+    rn = np.stack([rs.choice(3600, half, replace=False) for _ in range(n)])
+    vals = {}
+    for dtype in ('f16', 'f32'):
+        net = _net('DenseBox', dtype)
+        with torch.no_grad():
+            full = float(net.loss(net(x), bbox, rand_neg_indices=rn, batch_global=n, positive_num_global=p_global))
+            parts = sum(float(net.loss(net(x[lo:lo + 16]), bbox[lo:lo + 16], rand_neg_indices=rn[lo:lo + 16], batch_global=n,
+                                       positive_num_global=p_global)) for lo in range(0, n, 16))
+        assert np.isfinite(full) and abs(parts - full) <= 1e-5 * abs(full), (dtype, full, parts)
+        vals[dtype] = full
+    assert abs(vals['f16'] - vals['f32']) <= 2e-2 * abs(vals['f32']), vals
