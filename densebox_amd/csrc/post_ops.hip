@@ -292,3 +292,80 @@ extern "C" int dbx_nms(const double* dets, int32_t n, int32_t det_cols, double n
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- plate rectification
+// perspective_transform (DenseBox.py:3446-3481): homography from the four landmark corners to their axis-aligned bounding
+// rectangle (cv2.getPerspectiveTransform) and a warp of the whole image to 1.5x its size (cv2.warpPerspective, default
+// INTER_LINEAR, constant border 0).  OpenCV is not part of the reference tree (and not installed here), so both follow its
+// PUBLISHED algorithm (imgwarp.cpp): 8x8 system in double solved by LU with partial pivoting; inverse map through the
+// 3x3 inverse; source coordinates rounded to 1/32 pixel (INTER_BITS = 5); 8-bit bilinear weights in 15-bit fixed point,
+// (sum + 2^14) >> 15.  Parity with OpenCV itself is unpinned; the GPU kernel is bit-exact against oracle/.
+extern "C" int dbx_perspective_matrix(const float* src_xy, const float* dst_xy, double* m9) {
+    DBX_REQUIRE(src_xy && dst_xy && m9, "perspective_matrix: null argument");
+    double A[8][9];
+    for (int i = 0; i < 4; ++i) {
+        const double sx = src_xy[2 * i], sy = src_xy[2 * i + 1], dx = dst_xy[2 * i], dy = dst_xy[2 * i + 1];
+        const double r0[9] = {sx, sy, 1, 0, 0, 0, -sx * dx, -sy * dx, dx};
+        const double r1[9] = {0, 0, 0, sx, sy, 1, -sx * dy, -sy * dy, dy};
+        for (int j = 0; j < 9; ++j) { A[i][j] = r0[j]; A[i + 4][j] = r1[j]; }
+    }
+    for (int c = 0; c < 8; ++c) {                      // Gaussian elimination, partial pivoting (DECOMP_LU)
+        int piv = c;
+        for (int r = c + 1; r < 8; ++r) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
+        DBX_REQUIRE(fabs(A[piv][c]) > 2.220446049250313e-16, "perspective_matrix: degenerate corner configuration");
+        if (piv != c) for (int j = 0; j < 9; ++j) { const double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+        const double d = -1.0 / A[c][c];
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = A[r][c] * d;
+            for (int j = c + 1; j < 9; ++j) A[r][j] += f * A[c][j];
+        }
+    }
+    double x[8];
+    for (int r = 7; r >= 0; --r) {
+        double acc = A[r][8];
+        for (int j = r + 1; j < 8; ++j) acc -= A[r][j] * x[j];
+        x[r] = acc / A[r][r];
+    }
+    for (int i = 0; i < 8; ++i) m9[i] = x[i];
+    m9[8] = 1.0;
+    return DBX_OK;
+}
+
+struct WarpArgs { const unsigned char* src; unsigned char* dst; int sh, sw, c, dh, dw; double im[9]; };
+__global__ void warp_perspective_u8_kernel(const WarpArgs a) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.dw || y >= a.dh) return;
+    const double X0 = a.im[0] * x + a.im[1] * y + a.im[2], Y0 = a.im[3] * x + a.im[4] * y + a.im[5];
+    double W = a.im[6] * x + a.im[7] * y + a.im[8];
+    W = W != 0.0 ? 32.0 / W : 0.0;
+    const double fX = fmax(-2147483648.0, fmin(2147483647.0, X0 * W)), fY = fmax(-2147483648.0, fmin(2147483647.0, Y0 * W));
+    const int X = (int)rint(fX), Y = (int)rint(fY);                          // cvRound: nearest, ties to even
+    const int sx = X >> 5, sy = Y >> 5, ax = X & 31, ay = Y & 31;
+    const int w00 = (32 - ax) * (32 - ay) * 32, w01 = ax * (32 - ay) * 32, w10 = (32 - ax) * ay * 32, w11 = ax * ay * 32;
+    const bool x0 = sx >= 0 && sx < a.sw, x1 = sx + 1 >= 0 && sx + 1 < a.sw, y0 = sy >= 0 && sy < a.sh, y1 = sy + 1 >= 0 && sy + 1 < a.sh;
+    for (int ch = 0; ch < a.c; ++ch) {
+        const int p00 = (x0 && y0) ? a.src[((size_t)sy * a.sw + sx) * a.c + ch] : 0;
+        const int p01 = (x1 && y0) ? a.src[((size_t)sy * a.sw + sx + 1) * a.c + ch] : 0;
+        const int p10 = (x0 && y1) ? a.src[((size_t)(sy + 1) * a.sw + sx) * a.c + ch] : 0;
+        const int p11 = (x1 && y1) ? a.src[((size_t)(sy + 1) * a.sw + sx + 1) * a.c + ch] : 0;
+        const int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+        a.dst[((size_t)y * a.dw + x) * a.c + ch] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+extern "C" int dbx_warp_perspective_u8(const uint8_t* src, int32_t sh, int32_t sw, int32_t c, const double* m9, uint8_t* dst,
+                                       int32_t dh, int32_t dw, void* stream) {
+    DBX_REQUIRE(src && dst && m9 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && c >= 1 && c <= 4, "warp_perspective: bad arguments");
+    // inverse of the 3x3 map (dst -> src), cofactor form in double
+    const double* m = m9;
+    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    DBX_REQUIRE(det != 0.0, "warp_perspective: singular matrix");
+    const double d = 1.0 / det;
+    WarpArgs a;
+    a.src = src; a.dst = dst; a.sh = sh; a.sw = sw; a.c = c; a.dh = dh; a.dw = dw;
+    a.im[0] = (m[4] * m[8] - m[5] * m[7]) * d; a.im[1] = (m[2] * m[7] - m[1] * m[8]) * d; a.im[2] = (m[1] * m[5] - m[2] * m[4]) * d;
+    a.im[3] = (m[5] * m[6] - m[3] * m[8]) * d; a.im[4] = (m[0] * m[8] - m[2] * m[6]) * d; a.im[5] = (m[2] * m[3] - m[0] * m[5]) * d;
+    a.im[6] = (m[3] * m[7] - m[4] * m[6]) * d; a.im[7] = (m[1] * m[6] - m[0] * m[7]) * d; a.im[8] = (m[0] * m[4] - m[1] * m[3]) * d;
+    hipLaunchKernelGGL(warp_perspective_u8_kernel, dim3((dw + 255) / 256, dh), dim3(256), 0, (hipStream_t)stream, a);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}

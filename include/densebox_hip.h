@@ -220,6 +220,14 @@ int64_t dbx_detect_scratch_bytes(int32_t rows, int32_t cols, int32_t K);
 /* scratch: 5*n bytes */
 int dbx_nms(const double* dets, int32_t n, int32_t det_cols, double nms_thresh, int32_t* keep, void* scratch, void* stream);
 
+/* ---- plate rectification after decode (perspective_transform, DenseBox.py:3446-3481; OpenCV's published algorithm) ----
+ * dbx_perspective_matrix: host function, cv2.getPerspectiveTransform: 3x3 row-major double map src -> dst of four (x, y)
+ *   float pairs.  dbx_warp_perspective_u8: cv2.warpPerspective(img, M, (dw, dh)) with INTER_LINEAR and a zero border on an
+ *   interleaved uint8 image [h][w][c] (device pointers). */
+int dbx_perspective_matrix(const float* src_xy, const float* dst_xy, double* m9);
+int dbx_warp_perspective_u8(const uint8_t* src, int32_t sh, int32_t sw, int32_t c, const double* m9, uint8_t* dst,
+                            int32_t dh, int32_t dw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

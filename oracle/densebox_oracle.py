@@ -423,3 +423,84 @@ def normalize_u8(u8_nhwc):
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
     return (x - mean) / std
+
+
+# ------------------------------------------------------------------------------------------------ plate rectification
+# perspective_transform (DenseBox.py:3446-3481) delegates to cv2.getPerspectiveTransform / cv2.warpPerspective.  OpenCV
+# (no version pinned by the reference; not installed here, not under /root/reference) is restated from its published
+# algorithm (modules/imgproc/src/imgwarp.cpp): PARITY WITH OPENCV ITSELF IS UNPINNED -- this restatement pins the HIP kernel.
+def perspective_dst_rectangle(src_pts):
+    lu, ru, rd, ld = src_pts
+    min_x, max_x = min(lu[0], ld[0]), max(ru[0], rd[0])
+    min_y, max_y = min(lu[1], ru[1]), max(ld[1], rd[1])
+    return [[min_x, min_y], [max_x, min_y], [max_x, max_y], [min_x, max_y]]
+
+
+def get_perspective_matrix(src_pts, dst_pts):
+    """8x8 system in float64, Gaussian elimination with partial pivoting (cv::solve DECOMP_LU); M[2][2] = 1."""
+    src = np.float32(src_pts).astype(np.float64).reshape(4, 2)
+    dst = np.float32(dst_pts).astype(np.float64).reshape(4, 2)
+    A = np.zeros((8, 9), dtype=np.float64)
+    for i in range(4):
+        sx, sy, dx, dy = src[i, 0], src[i, 1], dst[i, 0], dst[i, 1]
+        A[i] = [sx, sy, 1, 0, 0, 0, -sx * dx, -sy * dx, dx]
+        A[i + 4] = [0, 0, 0, sx, sy, 1, -sx * dy, -sy * dy, dy]
+    for c in range(8):
+        piv = c
+        for r in range(c + 1, 8):
+            if abs(A[r, c]) > abs(A[piv, c]):
+                piv = r
+        if piv != c:
+            A[[c, piv]] = A[[piv, c]]
+        d = -1.0 / A[c, c]
+        for r in range(c + 1, 8):
+            f = A[r, c] * d
+            for j in range(c + 1, 9):
+                A[r, j] = A[r, j] + f * A[c, j]
+    x = np.zeros(8, dtype=np.float64)
+    for r in range(7, -1, -1):
+        acc = A[r, 8]
+        for j in range(r + 1, 8):
+            acc = acc - A[r, j] * x[j]
+        x[r] = acc / A[r, r]
+    return np.concatenate([x, [1.0]]).reshape(3, 3)
+
+
+def warp_perspective_u8(img, M, dsize):
+    """INTER_LINEAR, BORDER_CONSTANT 0: inverse map, coordinates rounded to 1/32 pixel, 15-bit fixed-point weights."""
+    img = np.asarray(img, dtype=np.uint8)
+    h, w, c = img.shape
+    dw, dh = int(dsize[0]), int(dsize[1])
+    m = np.asarray(M, dtype=np.float64).reshape(9)
+    det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6])
+    d = 1.0 / det
+    im = np.array([(m[4] * m[8] - m[5] * m[7]) * d, (m[2] * m[7] - m[1] * m[8]) * d, (m[1] * m[5] - m[2] * m[4]) * d,
+                   (m[5] * m[6] - m[3] * m[8]) * d, (m[0] * m[8] - m[2] * m[6]) * d, (m[2] * m[3] - m[0] * m[5]) * d,
+                   (m[3] * m[7] - m[4] * m[6]) * d, (m[1] * m[6] - m[0] * m[7]) * d, (m[0] * m[4] - m[1] * m[3]) * d])
+    xs = np.arange(dw, dtype=np.float64)[None, :]
+    ys = np.arange(dh, dtype=np.float64)[:, None]
+    X0 = (im[0] * xs + im[1] * ys) + im[2]
+    Y0 = (im[3] * xs + im[4] * ys) + im[5]
+    W = (im[6] * xs + im[7] * ys) + im[8]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        W = np.where(W != 0.0, 32.0 / W, 0.0)
+    fX = np.maximum(-2147483648.0, np.minimum(2147483647.0, X0 * W))
+    fY = np.maximum(-2147483648.0, np.minimum(2147483647.0, Y0 * W))
+    X = np.rint(fX).astype(np.int64)
+    Y = np.rint(fY).astype(np.int64)
+    sx, sy, ax, ay = X >> 5, Y >> 5, X & 31, Y & 31
+    w00, w01, w10, w11 = (32 - ax) * (32 - ay) * 32, ax * (32 - ay) * 32, (32 - ax) * ay * 32, ax * ay * 32
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        v = img[np.clip(yy, 0, h - 1), np.clip(xx, 0, w - 1)].astype(np.int64)
+        return np.where(ok[..., None], v, 0)
+    acc = (tap(sy, sx) * w00[..., None] + tap(sy, sx + 1) * w01[..., None] + tap(sy + 1, sx) * w10[..., None] +
+           tap(sy + 1, sx + 1) * w11[..., None] + (1 << 14)) >> 15
+    return np.clip(acc, 0, 255).astype(np.uint8)
+
+
+def perspective_transform(img, src_pts):
+    M = get_perspective_matrix(src_pts, perspective_dst_rectangle(src_pts))
+    h, w = img.shape[0], img.shape[1]
+    return warp_perspective_u8(img, M, (int(w * 1.5 + 0.5), int(h * 1.5 + 0.5)))
