@@ -123,8 +123,8 @@ def measured_peaks(dev, dtype):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--kind', default='DenseBoxLMLOC', choices=list(FWD_GFLOP))
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
     ap.add_argument('--batch', type=int, default=64, help='patches per GPU')
