@@ -14,6 +14,8 @@ DTYPE_ID = {'f16': F16, 'bf16': BF16, 'f32': F32}
 ESIZE = {F16: 2, BF16: 2, F32: 4}
 
 EPI_BIAS, EPI_RELU, EPI_GATE, EPI_DROPMASK, EPI_ACCUM, EPI_F32_NCHW, EPI_DROPHASH = 1, 2, 4, 8, 16, 32, 64
+CONV_WFRAG = 128          # w_packed is in MFMA-fragment order (pack modes 4/5)
+K_IGEMM, K_DMA, K_BAND, K_C64, K_C8, K_WS = 1, 2, 3, 4, 5, 6
 
 
 class View(C.Structure):
@@ -24,6 +26,11 @@ class View(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [('dtype', C.c_int32), ('kh', C.c_int32), ('kw', C.c_int32), ('cpad', C.c_int32),
                 ('cin_pad', C.c_int32), ('cout_pad', C.c_int32), ('epilogue', C.c_int32), ('drop_seed', C.c_uint32)]
+
+
+class ConvPlan(C.Structure):
+    _fields_ = [('kernel', C.c_int32), ('tile_m', C.c_int32), ('tile_n', C.c_int32), ('w_frag', C.c_int32),
+                ('name', C.c_char * 64)]
 
 
 class LossDesc(C.Structure):
@@ -51,6 +58,7 @@ SIGNATURES = {
     'dbx_device_arch': (C.c_int, [C.c_int]),
     'dbx_conv_packed_elems': (_I64, [_PC]),
     'dbx_conv_forward': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _VP, _I32, _VP]),
+    'dbx_conv_plan': (C.c_int, [_PC, _PV, _PV, C.POINTER(ConvPlan)]),
     'dbx_conv_forward_split': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _PV, _PV, _I32, _I32, _VP]),
     'dbx_pack_weight': (C.c_int, [_I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
     'dbx_fold_heads': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP]),

@@ -21,8 +21,16 @@ class NetFunction(torch.autograd.Function):
             raise RuntimeError('densebox_amd: backward() after another forward() on the same module -- the '
                                'activations of this graph were overwritten (one graph in flight per module)')
         G = eng.backward_raw(dict(zip(ctx.names, grads)))
-        if eng.grad_sink is not None:
-            # data-parallel: gradients live in the reducer's flat buffer and are still being all-reduced;
-            # dist.DataParallel.step() attaches them as .grad once the collective is enqueued behind them
-            return (None, None) + (None,) * len(ctx.pnames)
+        sink = eng.grad_sink
+        if sink is not None:
+            if getattr(sink, 'in_step', False):
+                # data-parallel: gradients live in the reducer's flat buffer and are still being all-reduced;
+                # dist.DataParallel.step() attaches them as .grad once the collective is enqueued behind them
+                return (None, None) + (None,) * len(ctx.pnames)
+            # the reference loop body (net(x); loss.backward(); opt.step()) on a module wrapped by DataParallel
+            if sink.world > 1:
+                raise RuntimeError('densebox_amd: this module is wrapped by dist.DataParallel -- its gradients are produced and '
+                                   'all-reduced inside DataParallel.step(); call that (or DataParallel.close() first) instead '
+                                   'of loss.backward()')
+            return (None, None) + tuple(sink.views.get(n) for n in ctx.pnames)
         return (None, None) + tuple(G.get(n) for n in ctx.pnames)

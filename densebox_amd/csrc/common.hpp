@@ -86,6 +86,17 @@ __device__ __forceinline__ unsigned dbx_drop_bits4(unsigned seed, unsigned m, un
     return x;
 }
 
+// Fragment-order weight image of a 3x3 layer (conv3x3_ws.hpp; dbx_pack_weight modes 4/5): element (row, tap = 3 ky + kx, k) at
+//   [row / BN][period = ky * KC + k / 64][step = kx * 4 + (k % 64) / 16][(row % BN) / 32][lane = 32 * ((k % 16) / 8) + row % 32][k % 8]
+__host__ __device__ inline size_t dbx_frag_index(int row, int tap, int k, int cin_pad, int rows_pad) {
+    const int bn = rows_pad % 256 == 0 ? 256 : 128;
+    const int KC = cin_pad / 64, ky = tap / 3, kx = tap - 3 * ky;
+    const int period = ky * KC + k / 64, step = kx * 4 + (k % 64) / 16;
+    const int lane = 32 * ((k % 16) / 8) + row % 32;
+    const size_t blk = (((size_t)(row / bn) * (3 * KC) + period) * 12 + step) * (bn / 32) + (row % bn) / 32;
+    return (blk * 64 + lane) * 8 + k % 8;
+}
+
 #define DBX_DISPATCH_DTYPE(dtype, FN, ...)                          \
     switch (dtype) {                                                \
         case DBX_F16: return FN<_Float16>(__VA_ARGS__);             \

@@ -16,6 +16,7 @@
 // flipped/transposed packed weights -- every dgrad.
 #include "common.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 struct ConvArgs {
     const char* x;       // framed input, pointing at pixel (0,-pad,-pad) channel c_off
@@ -724,6 +725,12 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
     }
 }
 
+#include "conv3x3_pipe.hpp"
+#ifdef DBX_LAB
+#include "conv3x3_pw4.hpp"
+#endif
+#include "conv3x3_ws.hpp"
+
 // ------------------------------------------------------------------------------------------------ v4: 64 -> 64 channels, 3x3
 // conv1_2 (forward and dgrad) at 240x240: N = 64 couts is too narrow for the band kernel -- every 512-pixel tile re-stages
 // its A band six times (3 ky x 2 K chunks) plus the weights: 270 KB of LDS fill per 512 pixels, fill-bound at 540 TFLOP/s.
@@ -1078,8 +1085,15 @@ static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s
     return DBX_OK;
 }
 
+static bool ws_enabled() {           // DBX_WS=0 keeps the LDS band kernels on every layer (A/B testing)
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("DBX_WS"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
+static int g_conv_variant_override = -1;   // set by in-tree lab programs that include this file (tools/band_lab.hip)
 static int conv_variant() {          // DBX_CONV_VARIANT=1 forces the register-staged v1 kernel everywhere (A/B testing)
     static int v = -1;
+    if (g_conv_variant_override >= 0) return g_conv_variant_override;
     if (v < 0) { const char* e = getenv("DBX_CONV_VARIANT"); v = e ? atoi(e) : 0; }
     return v;
 }
@@ -1087,8 +1101,20 @@ static int conv_variant() {          // DBX_CONV_VARIANT=1 forces the register-s
 template <typename T>
 static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void* w, const float* bias,
                           const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int dm_ld, hipStream_t s,
-                          const dbx_view* y2 = nullptr, const dbx_view* gate2 = nullptr, int split_c = 0, int epi2 = 0) {
+                          const dbx_view* y2 = nullptr, const dbx_view* gate2 = nullptr, int split_c = 0, int epi2 = 0,
+                          dbx_conv_plan_t* plan = nullptr) {
     constexpr int ES = sizeof(T);
+    // One selection path for launching and for dbx_conv_plan(): with `plan` set, the chosen kernel is reported instead of launched.
+    static const char* const tname = sizeof(T) == 4 ? "f32" : (DType<T>::id == DBX_F16 ? "f16" : "bf16");
+#define DBX_SELECT(ID, TM, TN, NAME, CALL)                                                                   \
+    do {                                                                                                     \
+        if (plan) {                                                                                          \
+            plan->kernel = ID; plan->tile_m = TM; plan->tile_n = TN; plan->w_frag = (ID) == DBX_K_WS ? 1 : 0; \
+            snprintf(plan->name, sizeof plan->name, NAME "<%s,%d,%d>", tname, TM, TN);                      \
+            return DBX_OK;                                                                                   \
+        }                                                                                                    \
+        return CALL;                                                                                         \
+    } while (0)
     const int ho = x->h + 2 * d->cpad - d->kh + 1, wo = x->w + 2 * d->cpad - d->kw + 1;
     DBX_REQUIRE(ho == y->h && wo == y->w && x->n == y->n, "conv: output %dx%d does not match %dx%d", y->h, y->w, ho, wo);
     DBX_REQUIRE(x->pad >= d->cpad, "conv: input frame %d < conv padding %d", x->pad, d->cpad);
@@ -1101,9 +1127,11 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     const bool nchw = d->epilogue & DBX_EPI_F32_NCHW;
     if (!nchw) DBX_REQUIRE(y->c % 4 == 0 && ((y->c_off * ES) % 8) == 0 && (y->ld * ES) % 8 == 0, "conv: y alignment");
     DBX_REQUIRE(y->c <= d->cout_pad, "conv: y has more channels than the packed weight");
-    if (d->epilogue & DBX_EPI_GATE) DBX_REQUIRE(gate && gate->h == y->h && gate->w == y->w && gate->c >= y->c, "conv: bad gate view");
-    if (d->epilogue & DBX_EPI_DROPMASK) DBX_REQUIRE(dropmask && dm_ld % 4 == 0, "conv: bad dropout mask");
-    if (d->epilogue & DBX_EPI_BIAS) DBX_REQUIRE(bias != nullptr, "conv: bias missing");
+    if (!plan) {
+        if (d->epilogue & DBX_EPI_GATE) DBX_REQUIRE(gate && gate->h == y->h && gate->w == y->w && gate->c >= y->c, "conv: bad gate view");
+        if (d->epilogue & DBX_EPI_DROPMASK) DBX_REQUIRE(dropmask && dm_ld % 4 == 0, "conv: bad dropout mask");
+        if (d->epilogue & DBX_EPI_BIAS) DBX_REQUIRE(bias != nullptr, "conv: bias missing");
+    }
 
     ConvArgs a;
     a.x = (const char*)x->ptr + (size_t)x->c_off * ES;
@@ -1121,7 +1149,7 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.ktot_bytes = (int)(packed_k_elems(d) * ES);
     a.ksteps = a.ktot_bytes / 128;
     a.cout_valid = y->c;
-    a.epi = d->epilogue; a.dm_ld = dm_ld; a.drop_seed = d->drop_seed;
+    a.epi = d->epilogue & ~DBX_CONV_WFRAG; a.dm_ld = dm_ld; a.drop_seed = d->drop_seed;
     a.y2 = nullptr; a.gate2 = nullptr; a.split_c = 0; a.epi2 = 0; a.cout_valid2 = 0;
     a.y2_hp = a.y2_wp = a.y2_ld = a.y2_pad = a.g2_hp = a.g2_wp = a.g2_ld = a.g2_pad = 0;
     if (y2) {
@@ -1142,8 +1170,31 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     }
     DBX_REQUIRE(a.M > 0 && (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < (int64_t)1 << 40, "conv: empty or oversized input");
 
+    // 3x3 / pad 1 on congruent frames, 16-bit, wide layers with enough tiles to fill the chip: register-streamed weights
+    // (conv3x3_ws.hpp).  It needs the weights in fragment order: a launch takes it iff the caller says so (DBX_CONV_WFRAG),
+    // dbx_conv_plan() reports it whenever the problem qualifies.
+    {
+        const bool wfrag = d->epilogue & DBX_CONV_WFRAG;
+        bool ws_ok = !smallc && sizeof(T) == 2 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 && ws_enabled() &&
+                     !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK | DBX_EPI_DROPHASH)) && !y2 &&
+                     d->cin_pad % 64 == 0 && d->cin_pad >= 128 && y->c == d->cout_pad && d->cout_pad % 128 == 0 &&
+                     (x->c_off * ES) % 128 == 0 && (y->c_off * ES) % 16 == 0 && (y->ld * ES) % 16 == 0;
+        const int wm = d->cout_pad % 256 == 0 ? 1 : 2;
+        const long long qtot = (long long)x->n * x->h * a.x_wp;
+        if (ws_ok) {
+            ws_ok = (long long)x->h * a.x_wp >= 256 * wm + 8 && qtot < (1ll << 30) &&                   // one image seam per tile
+                    (qtot / (256 * wm)) * (y->c / (256 / wm)) >= 192;                                       // fills the chip
+            if ((d->epilogue & DBX_EPI_GATE) && gate) ws_ok = ws_ok && (gate->c_off * ES) % 16 == 0 && (gate->ld * ES) % 16 == 0;
+        }
+        if (wfrag) DBX_REQUIRE(ws_ok, "conv: DBX_CONV_WFRAG weights, but the problem does not qualify for the ws kernel (ask dbx_conv_plan)");
+        if (ws_ok && (wfrag || plan)) {
+            a.ntile_n = y->c / (256 / wm);
+            if (wm == 1) DBX_SELECT(DBX_K_WS, 256, 256, "conv3x3_ws_kernel", (launch_conv_ws<T, 1>(a, x->n, x->h, s)));
+            DBX_SELECT(DBX_K_WS, 512, 128, "conv3x3_ws_kernel", (launch_conv_ws<T, 2>(a, x->n, x->h, s)));
+        }
+    }
     // 3x3 / pad 1 on congruent frames (x.pad == 1), 16-bit, plain NHWC epilogue: the band kernel over the linearised frame
-    if (!smallc && sizeof(T) == 2 && (conv_variant() == 0 || conv_variant() == 4) && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 &&
+    if (!smallc && sizeof(T) == 2 && (conv_variant() == 0 || conv_variant() >= 4) && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 &&
         !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK | DBX_EPI_DROPHASH)) && (d->cin_pad * ES) % 64 == 0 && y->c % 64 == 0) {
         const long long Q = (long long)x->n * a.x_hp * a.x_wp;
         const int tiles256 = (int)((Q + 255) / 256), tiles512 = (int)((Q + 511) / 512);
@@ -1154,22 +1205,25 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         const bool few256 = (long long)tiles256 * (y->c / 256) < want, few128 = (long long)tiles256 * (y->c / 128) < want;
         if (y->c % 256 == 0 && d->cout_pad % 256 == 0 && !few256) {
             a.ntile_n = y->c / 256; a.nblocks = tiles256 * a.ntile_n;
-            return launch_conv_band<T, 256, 256, 2, 2, 4>(a, s);
+#ifdef DBX_LAB
+            if (conv_variant() == 5 && (d->cin_pad * ES) % 128 == 0) return launch_conv_pipe<T, 5>(a, s);
+#endif
+            DBX_SELECT(DBX_K_BAND, 256, 256, "conv3x3_band_kernel", (launch_conv_band<T, 256, 256, 2, 2, 4>(a, s)));
         }
         if (y->c % 128 == 0 && d->cout_pad % 128 == 0 && (!few128 || y->c == 128)) {
             a.ntile_n = y->c / 128;
-            if (tall) { a.nblocks = tiles512 * a.ntile_n; return launch_conv_band<T, 512, 128, 2, 4, 2>(a, s); }
+            if (tall) { a.nblocks = tiles512 * a.ntile_n; DBX_SELECT(DBX_K_BAND, 512, 128, "conv3x3_band_kernel", (launch_conv_band<T, 512, 128, 2, 4, 2>(a, s))); }
             a.nblocks = tiles256 * a.ntile_n;
-            return launch_conv_band<T, 256, 128, 3, 4, 2>(a, s);
+            DBX_SELECT(DBX_K_BAND, 256, 128, "conv3x3_band_kernel", (launch_conv_band<T, 256, 128, 3, 4, 2>(a, s)));
         }
         // 64 -> 64 channels on big maps: weights-stationary halo-tile kernel (DBX_CONV_VARIANT=4 keeps the band kernel)
         if (d->cin_pad == 64 && d->cout_pad == 64 && y->c == 64 && x->c >= 64 && a.ktot_bytes == 1152 && conv_variant() != 4 &&
             (long long)x->n * ((x->h + 7) / 8) * ((x->w + 31) / 32) >= 256)             // at least one 8x32 tile per CU
-            return launch_conv_c64<T>(a, x->n, x->h, x->w, s);
+            DBX_SELECT(DBX_K_C64, 256, 64, "conv3x3_c64_kernel", (launch_conv_c64<T>(a, x->n, x->h, x->w, s)));
         a.ntile_n = y->c / 64;
-        if (tall) { a.nblocks = tiles512 * a.ntile_n; return launch_conv_band<T, 512, 64, 3, 8, 1>(a, s); }
+        if (tall) { a.nblocks = tiles512 * a.ntile_n; DBX_SELECT(DBX_K_BAND, 512, 64, "conv3x3_band_kernel", (launch_conv_band<T, 512, 64, 3, 8, 1>(a, s))); }
         a.nblocks = tiles256 * a.ntile_n;
-        return launch_conv_band<T, 256, 64, 4, 8, 1>(a, s);
+        DBX_SELECT(DBX_K_BAND, 256, 64, "conv3x3_band_kernel", (launch_conv_band<T, 256, 64, 4, 8, 1>(a, s)));
     }
     // LDS-DMA ring kernel: any non-small-Cin layer (f16/bf16/f32 alike); 256x128 tiles, 256x64 when the layer has 64 couts
     if (!smallc && conv_variant() != 1 && a.ksteps >= 2) {
@@ -1177,45 +1231,57 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         if (n64) {
             a.ntile_n = y->c <= 64 ? 1 : d->cout_pad / 64;
             a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
-            return launch_conv_dma<T, 256, 64, 128, 3, 8, 1>(a, s);
+            DBX_SELECT(DBX_K_DMA, 256, 64, "conv_igemm_dma_kernel", (launch_conv_dma<T, 256, 64, 128, 3, 8, 1>(a, s)));
         }
         if (y2) {                                                                    // split destination: 256x256 tiles over both
             a.ntile_n = (split_c + y2->c + 255) / 256;
             a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
-            return launch_conv_dma<T, 256, 256, 64, 4, 2, 4>(a, s);
+            DBX_SELECT(DBX_K_DMA, 256, 256, "conv_igemm_dma_kernel", (launch_conv_dma<T, 256, 256, 64, 4, 2, 4>(a, s)));
         }
         if (d->cout_pad % 256 == 0 && y->c % 256 == 0 && conv_variant() != 2) {      // wide layers: 256x256 tile
             a.ntile_n = y->c / 256;
             a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
-            return launch_conv_dma<T, 256, 256, 64, 4, 2, 4>(a, s);
+            DBX_SELECT(DBX_K_DMA, 256, 256, "conv_igemm_dma_kernel", (launch_conv_dma<T, 256, 256, 64, 4, 2, 4>(a, s)));
         }
         a.ntile_n = (y->c + 127) / 128;
         a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
-        return launch_conv_dma<T, 256, 128, 128, 3, 4, 2>(a, s);
+        DBX_SELECT(DBX_K_DMA, 256, 128, "conv_igemm_dma_kernel", (launch_conv_dma<T, 256, 128, 128, 3, 4, 2>(a, s)));
     }
     // conv1_1: one chunk per pixel, 64 couts, plain bias/ReLU epilogue, big maps: halo-tile kernel
     if (smallc && sizeof(T) == 2 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 && d->cout_pad == 64 && y->c == 64 &&
         x->ld * ES == 16 && !(d->epilogue & ~(DBX_EPI_BIAS | DBX_EPI_RELU)) && a.ktot_bytes == 256 && conv_variant() == 0 &&
         (long long)x->n * ((x->h + 7) / 8) * ((x->w + 31) / 32) >= 256)
-        return launch_conv_c8<T>(a, x->n, x->h, x->w, s);
+        DBX_SELECT(DBX_K_C8, 256, 64, "conv3x3_c8_kernel", (launch_conv_c8<T>(a, x->n, x->h, x->w, s)));
     // tile choice: couts are tiled by 128 unless the layer has 64 (or the result is tiny, e.g. the 512->k heads)
     const bool narrow = (d->cout_pad % 128 != 0) || y->c <= 64;
     if (narrow) {
         a.ntile_n = d->cout_pad / 64;
         if (y->c <= 64) a.ntile_n = 1;
         a.nblocks = ((a.M + 255) / 256) * a.ntile_n;
-        return smallc ? launch_conv<T, 256, 64, 4, 1, true>(a, s) : launch_conv<T, 256, 64, 4, 1, false>(a, s);
+        DBX_SELECT(DBX_K_IGEMM, 256, 64, "conv_igemm_kernel", (smallc ? launch_conv<T, 256, 64, 4, 1, true>(a, s) : launch_conv<T, 256, 64, 4, 1, false>(a, s)));
     }
     a.ntile_n = (y->c + 127) / 128;
     a.nblocks = ((a.M + 127) / 128) * a.ntile_n;
-    return smallc ? launch_conv<T, 128, 128, 2, 2, true>(a, s) : launch_conv<T, 128, 128, 2, 2, false>(a, s);
+    DBX_SELECT(DBX_K_IGEMM, 128, 128, "conv_igemm_kernel", (smallc ? launch_conv<T, 128, 128, 2, 2, true>(a, s) : launch_conv<T, 128, 128, 2, 2, false>(a, s)));
 }
+
+#undef DBX_SELECT
 
 extern "C" int dbx_conv_forward(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
                                 const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int32_t dropmask_ld,
                                 void* stream) {
     if (!d || !x || !y || !w_packed) { dbx_set_error("conv: null argument"); return DBX_ERR_ARG; }
     DBX_DISPATCH_DTYPE(d->dtype, conv_forward_t, d, x, w_packed, bias, y, gate, dropmask, dropmask_ld, (hipStream_t)stream);
+}
+
+template <typename T>
+static int conv_plan_t(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y, dbx_conv_plan_t* out) {
+    return conv_forward_t<T>(d, x, nullptr, nullptr, y, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, out);
+}
+extern "C" int dbx_conv_plan(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y, dbx_conv_plan_t* out) {
+    if (!d || !x || !y || !out) { dbx_set_error("conv plan: null argument"); return DBX_ERR_ARG; }
+    memset(out, 0, sizeof *out);
+    DBX_DISPATCH_DTYPE(d->dtype, conv_plan_t, d, x, y, out);
 }
 
 extern "C" int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
@@ -1229,7 +1295,7 @@ extern "C" int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x,
 // ------------------------------------------------------------------------------------------------ weight packing
 template <typename T>
 __global__ void pack_weight_kernel(const float* __restrict__ w, int co, int ci, int taps, int mode,
-                                   T* __restrict__ wp, int64_t ktot, int cin_pad, int row_off, int k_off) {
+                                   T* __restrict__ wp, int64_t ktot, int cin_pad, int row_off, int k_off, int rows_pad) {
     const int64_t total = (int64_t)co * ci * taps;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int t = (int)(i % taps);
@@ -1237,7 +1303,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int co, int ci, 
         const int o = (int)(i / ((int64_t)taps * ci));
         const float v = w[i];
         if (mode == 0) wp[(int64_t)(row_off + o) * ktot + (int64_t)t * cin_pad + k_off + c] = from_f32<T>(v);
-        else wp[(int64_t)(row_off + c) * ktot + (int64_t)(taps - 1 - t) * cin_pad + k_off + o] = from_f32<T>(v);
+        else if (mode == 1) wp[(int64_t)(row_off + c) * ktot + (int64_t)(taps - 1 - t) * cin_pad + k_off + o] = from_f32<T>(v);
+        else if (mode == 4) wp[dbx_frag_index(row_off + o, t, k_off + c, cin_pad, rows_pad)] = from_f32<T>(v);
+        else wp[dbx_frag_index(row_off + c, taps - 1 - t, k_off + o, cin_pad, rows_pad)] = from_f32<T>(v);
     }
 }
 
@@ -1246,12 +1314,16 @@ static int pack_weight_t(int mode, const float* w, int co, int ci, int kh, int k
                          int row_off, int k_off, hipStream_t s) {
     dbx_conv_desc d; d.dtype = DType<T>::id; d.kh = kh; d.kw = kw; d.cin_pad = cin_pad; d.cout_pad = rows_pad; d.drop_seed = 0;
     const int64_t ktot = packed_k_elems(&d);
-    const int rows = mode == 0 ? co : ci, cols = mode == 0 ? ci : co;
+    DBX_REQUIRE(mode == 0 || mode == 1 || mode == 4 || mode == 5, "pack_weight: mode %d", mode);
+    const bool fwd = mode == 0 || mode == 4;
+    const int rows = fwd ? co : ci, cols = fwd ? ci : co;
     DBX_REQUIRE(row_off + rows <= rows_pad && k_off + cols <= cin_pad, "pack_weight: slice out of range");
+    if (mode >= 4) DBX_REQUIRE(sizeof(T) == 2 && kh == 3 && kw == 3 && rows_pad % 128 == 0 && cin_pad % 64 == 0,
+                               "pack_weight: fragment order needs a 16-bit 3x3 layer, rows_pad %% 128 == 0, cin_pad %% 64 == 0");
     const int64_t total = (int64_t)co * ci * kh * kw;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, s, w, co, ci, kh * kw, mode, (T*)wp, ktot,
-                       cin_pad, row_off, k_off);
+                       cin_pad, row_off, k_off, rows_pad);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }

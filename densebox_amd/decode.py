@@ -61,6 +61,9 @@ def NMS(dets, nms_thresh=0.4):
     return [int(v) for v in k[1:1 + int(k[0])]]
 
 
+_MAX_GRAPHS = 8
+
+
 def _detect_eager(net, image, K, nms_thresh):
     M, N = image.size(2), image.size(3)
     with torch.no_grad():
@@ -88,7 +91,8 @@ def detect(net, image, K=10, nms_thresh=0.4):
     if not use_graph:
         dets, keep = _detect_eager(net, image, K, nms_thresh)
     else:
-        cache = net.__dict__.setdefault('_detect_graphs', {})
+        import collections
+        cache = net.__dict__.setdefault('_detect_graphs', collections.OrderedDict())
         sig = tuple((p._version, p.data_ptr()) for p in net.parameters())
         key = (tuple(image.shape), image.dtype, K, float(nms_thresh), getattr(net, 'compute_dtype', None))
         ent = cache.get(key)
@@ -100,9 +104,15 @@ def detect(net, image, K=10, nms_thresh=0.4):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 dets, keep = _detect_eager(net, static_in, K, nms_thresh)
-            ent = (sig, g, static_in, dets, keep)
+            # The captured kernels hold RAW pointers into the engine's workspace plan and packed / folded weight buffers.  The
+            # engine keeps one plan and re-creates its weight caches when the dtype or mode flips, so the entry pins every
+            # tensor it captured: a later forward at another shape (or a train-mode step) cannot free what a replay reads.
+            ent = (sig, g, static_in, dets, keep, net._engine.captured_refs())
             cache[key] = ent
-        _, g, static_in, dets, keep = ent
+            while len(cache) > _MAX_GRAPHS:            # bounded: one graph + private pool + pinned workspace per shape
+                cache.popitem(last=False)
+        cache.move_to_end(key)
+        _, g, static_in, dets, keep, _refs = ent
         static_in.copy_(image)
         g.replay()
     k = keep.cpu().numpy()

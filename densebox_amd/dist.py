@@ -66,6 +66,8 @@ class GradReducer:
         assert hi - lo == sum(self.range[n][1] - self.range[n][0] for n in names), 'parameters are not adjacent'
         return self.flat[lo:hi]
 
+    in_step = False          # True while DataParallel.step() drives the backward (autograd then returns no gradients)
+
     def begin(self):
         self._ready_hi = self._sent_hi = 0
         self._works = []
@@ -110,6 +112,12 @@ class DataParallel:
         self.reducer = GradReducer(net.named_parameters(), eng.grad_order(), bucket_bytes)
         eng.grad_sink = self.reducer
 
+    def close(self):
+        """Detach from the network: its engine writes gradients to ordinary tensors again (plain autograd training)."""
+        eng = self.net.engine()
+        if eng.grad_sink is self.reducer:
+            eng.grad_sink = None
+
     def global_positive_num(self, bbox, labels=None):
         from . import labels as LB
         p = int(LB.positive_count(bbox, labels).sum())
@@ -127,10 +135,15 @@ class DataParallel:
             positive_num_global = self.global_positive_num(bbox, labels if net.KIND == 'DenseBoxLMLOC' else None)
         self.opt.zero_grad(set_to_none=True)
         self.reducer.begin()
-        outs = net(x)
-        loss = net.loss(outs, bbox, vertices, labels, rand_neg_indices, lm_rand_neg_indices,
-                        batch_global=n_global, positive_num_global=positive_num_global, **loss_kw)
-        loss.backward()
+        net.engine().sample_offset = self.rank * x.size(0)     # ranks draw different dropout masks (engine._next_drop_seed)
+        self.reducer.in_step = True
+        try:
+            outs = net(x)
+            loss = net.loss(outs, bbox, vertices, labels, rand_neg_indices, lm_rand_neg_indices,
+                            batch_global=n_global, positive_num_global=positive_num_global, **loss_kw)
+            loss.backward()
+        finally:
+            self.reducer.in_step = False
         self.reducer.finish()
         for name, p in net.named_parameters():
             p.grad = self.reducer.views.get(name)          # None for conv3_3 (never executed)

@@ -25,6 +25,20 @@ _HEADS = {
 }
 
 
+# 3x3 backbone layer -> (input buffer, output buffer) of its forward conv and (dz buffer, dx buffer) of its data gradient
+_FWD_IO = {'conv1_1_1': ('x0', 'a11'), 'conv1_2_1': ('a11', 'a12'), 'conv2_1_1': ('p1', 'a21'), 'conv2_2_1': ('a21', 'a22'),
+           'conv3_1_1': ('p2', 'a31'), 'conv3_2_1': ('a31', 'a32'), 'conv3_4_1': ('a32', 'c34'), 'conv4_1_1': ('p3', 'a41'),
+           'conv4_2_1': ('a41', 'a42'), 'conv4_3_1': ('a42', 'a43'), 'conv4_4_1': ('a43', 'a44')}
+_BWD_IO = {'conv4_4_1': ('d_a44', 'd_a43'), 'conv4_3_1': ('d_a43', 'd_a42'), 'conv4_2_1': ('d_a42', 'd_a41'),
+           'conv4_1_1': ('d_a41', 'd_p3'), 'conv3_4_1': ('d_c34', 'd_a32'), 'conv3_2_1': ('d_a32', 'd_a31'),
+           'conv3_1_1': ('d_a31', 'd_p2'), 'conv2_2_1': ('d_a22', 'd_a21'), 'conv2_1_1': ('d_a21', 'd_p1'),
+           'conv1_2_1': ('d_a12', 'd_a11')}
+_CH = {s: (ci, co) for s, ci, co in [('conv1_1_1', 3, 64), ('conv1_2_1', 64, 64), ('conv2_1_1', 64, 128), ('conv2_2_1', 128, 128),
+                                     ('conv3_1_1', 128, 256), ('conv3_2_1', 256, 256), ('conv3_4_1', 256, 256),
+                                     ('conv4_1_1', 256, 512), ('conv4_2_1', 512, 512), ('conv4_3_1', 512, 512),
+                                     ('conv4_4_1', 512, 512)]}
+
+
 def _align(x, a=256):
     return (x + a - 1) // a * a
 
@@ -40,7 +54,8 @@ class Buf:
         self.bytes = n * self.hp * self.wp * c * self.es
         # guard band: the weight-gradient and 3x3 band kernels walk the frame linearly and read up to a tile (512+16
         # pixels) plus a frame row before/after it; keep those reads inside the (zeroed) allocation
-        self.guard = _align(max(4 * (self.wp + 2), 576 + self.wp) * c * self.es)
+        # (the register-streamed-weights conv reads a 520-pixel band + two skipped halo rows + a frame row past its last tile)
+        self.guard = _align(max(4 * (self.wp + 2), 576 + 4 * self.wp) * c * self.es)
         self.base = None     # device address of element (0,-pad,-pad,0)
 
     def view(self, c_off=0, c=None):
@@ -102,6 +117,7 @@ class Plan:
             off += _align(b.bytes) + b.guard
         self.total = off
         self.drop_active = self.drop_hash = False
+        self.frag = {}             # (stem, 'f' | 'b') -> fragment-order weights? (Engine._frag)
         self.drop_seed = 0
         self.mask_buf = None
         self.ws = torch.zeros(off, dtype=torch.uint8, device=device)
@@ -128,6 +144,7 @@ class Engine:
         self._table_keys = set()   # cache keys whose buffers the pack table refreshes
         self._tables = {}          # (dtype, train) -> (device job table, count, max_elems)
         self._wsig = None
+        self._plans_conv = {}      # problem signature -> (kernel id, name, fragment-order weights?) from dbx_conv_plan
 
     def grad_order(self):
         """Parameter names in the order backward_raw() finishes their gradients (deepest first)."""
@@ -167,7 +184,8 @@ class Engine:
         if self._defer is not None:       # table build: record the job, the multi-tensor launch does the work
             es = _lib.ESIZE[dt]
             ktot = (kh * kw * cin_pad * es + 127) // 128 * 128 // es
-            self._defer.append((w.data_ptr(), out.data_ptr(), co, ci, kh * kw, mode, ktot, cin_pad, row_off, k_off))
+            self._defer.append((w.data_ptr(), out.data_ptr(), co, ci, kh * kw, mode, rows_pad if mode >= 4 else ktot, cin_pad,
+                                row_off, k_off))
             self._defer_keep.append(out)
             return out
         check(self.L.dbx_pack_weight(dt, mode, ptr(w.detach()), co, ci, kh, kw, ptr(out), rows_pad, cin_pad,
@@ -194,11 +212,26 @@ class Engine:
         self.bias_cache[key] = (ver, b)
         return b
 
-    def _w_fwd(self, dt, stem, cin_pad, cout_pad):
+    def _w_fwd(self, dt, stem, cin_pad, cout_pad, frag=False):
+        """Packed forward weights; frag: MFMA-fragment order (pack mode 4) for the register-streamed-weights kernel."""
         w = self._param(stem + '.weight')
-        return self._packed((stem, 0, dt),
-                            lambda old: self._pack(dt, 0, w, cout_pad, cin_pad, w.shape[2], w.shape[3], out=old),
+        mode = 4 if frag else 0
+        return self._packed((stem, mode, dt),
+                            lambda old: self._pack(dt, mode, w, cout_pad, cin_pad, w.shape[2], w.shape[3], out=old),
                             (w._version, w.data_ptr()))
+
+    def conv_plan(self, dt, x, y, kh, kw, cpad, cin_pad, cout_pad, epi):
+        """The library's kernel choice for this problem (dbx_conv_plan): (ConvPlan.kernel, name, wants fragment-order weights)."""
+        key = (dt, x.n, x.h, x.w, x.pad, x.ld, x.c_off, x.c, y.pad, y.ld, y.c_off, y.c, kh, kw, cpad, cin_pad, cout_pad,
+               epi & ~_lib.CONV_WFRAG)
+        ent = self._plans_conv.get(key)
+        if ent is None:
+            d = ConvDesc(dt, kh, kw, cpad, cin_pad, cout_pad, epi & ~_lib.CONV_WFRAG, 0)
+            out = _lib.ConvPlan()
+            check(self.L.dbx_conv_plan(C.byref(d), C.byref(x), C.byref(y), C.byref(out)))
+            ent = (out.kernel, out.name.decode(), bool(out.w_frag))
+            self._plans_conv[key] = ent
+        return ent
 
     def _w_heads1(self, dt):
         heads = _HEADS[self.kind]
@@ -216,7 +249,7 @@ class Engine:
         heads = _HEADS[kind]
         nh = len(heads)
         for stem, cin, cout in _BACKBONE:
-            self._w_fwd(dt, stem, P.cin0 if cin == 3 else cin, max(64, cout))
+            self._w_fwd(dt, stem, P.cin0 if cin == 3 else cin, max(64, cout), frag=self._frag(P, dt, stem, 'f'))
             self._bias([stem], max(64, cout))
         self._w_heads1(dt)
         self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
@@ -229,7 +262,7 @@ class Engine:
             self._w_fwd(dt, 'conv6_3_det', 64, 64); self._bias(['conv6_3_det'], 64)
         if train:
             for stem, cin, cout in _BACKBONE[1:]:
-                self._w_bwd(dt, stem, max(64, cin), cout)
+                self._w_bwd(dt, stem, max(64, cin), cout, frag=self._frag(P, dt, stem, 'b'))
             self._w_heads1_bwd(dt)
             if kind != 'DenseBox':
                 self._w_bwd(dt, 'conv6_3_det', 64, P.crf)
@@ -239,10 +272,11 @@ class Engine:
     def _prepare_weights(self, dt, train, P):
         """Re-pack all parameters with ONE kernel launch when any of them changed (e.g. after an optimizer step)."""
         params = [p for _, p in self.net.named_parameters()]
-        sig = (dt, train, tuple((p._version, p.data_ptr()) for p in params))
+        lay = tuple(self._frag(P, dt, st, wh) for st, _, _ in _BACKBONE for wh in ('f', 'b'))   # layouts the kernels of this plan want
+        sig = (dt, train, tuple((p._version, p.data_ptr()) for p in params), lay)
         if sig == self._wsig:
             return
-        tkey = (dt, train, P.cin0, P.crf, sig[2][0][1])
+        tkey = (dt, train, P.cin0, P.crf, lay, tuple(dp for _, dp in sig[2]))   # the table stores EVERY parameter's pointer
         tab = self._tables.get(tkey)
         if tab is None:
             import numpy as np
@@ -291,6 +325,47 @@ class Engine:
         return wp, bf, ktot
 
     # ------------------------------------------------------------------ plumbing
+    def _frag(self, P, dt, stem, which):
+        """Does the library run this backbone layer's forward ('f') / data-gradient ('b') conv with fragment-order weights
+        (the register-streamed-weights kernel) under plan P?  Decided by dbx_conv_plan on the very views the call uses."""
+        key = (stem, which)
+        r = P.frag.get(key)
+        if r is None:
+            B = P.B
+            cin, cout = _CH[stem]
+
+            def vw(name):
+                return B['fusion'].view(512, 256) if name == 'c34' else B[name].view()
+            if which == 'f':
+                src, dst = _FWD_IO[stem]
+                cin_pad = P.cin0 if cin == 3 else cin
+                r = self.conv_plan(dt, vw(src), vw(dst), 3, 3, 1, cin_pad, max(64, cout), _lib.EPI_BIAS | _lib.EPI_RELU)[2]
+            else:
+                dz, dx = _BWD_IO[stem]
+                r = self.conv_plan(dt, vw(dz), vw(dx), 3, 3, 1, cout, max(64, cin), _lib.EPI_GATE)[2] if dz in B else False
+            P.frag[key] = r
+        return r
+
+    def _next_drop_seed(self):
+        """Per-step seed of the counter-based dropout hash.  The stream starts from torch.initial_seed() (torch.manual_seed
+        reproduces a run; reference: nn.Dropout draws from torch's generator, DenseBox.py:160) mixed with `sample_offset`
+        (the index of this rank's first patch in the global batch, set by dist.DataParallel), so ranks draw different masks."""
+        st = getattr(self, '_seed_state', None)
+        if st is None or st[0] != torch.initial_seed():
+            base = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5eed) & 0xffffffffffffffff
+            st = [torch.initial_seed(), (base ^ (base >> 32)) & 0xffffffff]
+            self._seed_state = st
+        st[1] = (st[1] * 1664525 + 1013904223) & 0xffffffff
+        x = (st[1] ^ (int(getattr(self, 'sample_offset', 0)) * 0x85EBCA6B)) & 0xffffffff
+        return x
+
+    def captured_refs(self):
+        """Strong references to every device buffer a just-captured hipGraph of this engine's launches points into (workspace
+        plan, packed / folded weights, biases, job tables).  decode.detect() stores them next to the graph: the engine keeps
+        ONE plan and rebuilds its weight caches on dtype / mode changes, which would otherwise free memory a replay reads."""
+        return (list(self.plans.values()), getattr(self, 'last_plan', None), dict(self.wcache), dict(self.bias_cache),
+                dict(self._tables))
+
     def plan(self, n, h, w, dt, device, train):
         key = (n, h, w, dt, train)
         p = self.plans.get(key)
@@ -311,23 +386,8 @@ class Engine:
                                       C.c_void_p(dropmask) if dropmask else None, dm_ld, stream_ptr()))
         if prof is not None:
             ev1.record()
-            # same tile rule as conv_igemm.hip::conv_forward_t; algorithmic FLOP = 2 * pixels * taps * Cin * Cout (real)
-            narrow = (cout_pad % 128 != 0) or y.c <= 64
-            small = cin_pad * _lib.ESIZE[dt] < 128
-            tn = ('f16', 'bf16', 'f32')[dt]
-            band = (not small) and dt != _lib.F32 and kh == 3 and kw == 3 and cpad == 1 and x.pad == 1 and \
-                not (epi & (_lib.EPI_F32_NCHW | _lib.EPI_DROPMASK)) and y.c % 64 == 0
-            if small:
-                name = 'conv_igemm_kernel<%s,%s,smallc>' % (tn, '256,64,4,1' if narrow else '128,128,2,2')
-            elif band:
-                bn = 256 if (y.c % 256 == 0 and cout_pad % 256 == 0) else (128 if (y.c % 128 == 0 and cout_pad % 128 == 0) else 64)
-                tall = bn < 256 and (x.n * (x.h + 2) * (x.w + 2) + 511) // 512 >= 1024
-                name = 'conv3x3_band_kernel<%s,%d,%d>' % (tn, 512 if tall else 256, bn)
-                if bn == 64 and cin_pad == 64 and cout_pad == 64 and x.n * ((x.h + 7) // 8) * ((x.w + 31) // 32) >= 256:
-                    name = 'conv3x3_c64_kernel<%s>' % tn
-            else:
-                wide = (not narrow) and cout_pad % 256 == 0 and y.c % 256 == 0
-                name = 'conv_igemm_dma_kernel<%s,%s>' % (tn, '256,64' if narrow else ('256,256' if wide else '256,128'))
+            # the kernel the library selected (dbx_conv_plan), algorithmic FLOP = 2 * pixels * taps * Cin * Cout (real)
+            name = self.conv_plan(dt, x, y, kh, kw, cpad, cin_pad, cout_pad, epi)[1]
             ci = alg_ci if alg_ci is not None else cin_pad
             prof.append({'kernel': name, 'flops': 2.0 * y.n * y.h * y.w * kh * kw * ci * y.c, 'start': ev0, 'end': ev1})
 
@@ -379,9 +439,11 @@ class Engine:
 
         def conv3(stem, src, dst, cin, cout, dst_view=None):
             cin_pad = P.cin0 if cin == 3 else cin
-            wp = self._w_fwd(dt, stem, cin_pad, max(64, cout))
+            frag = self._frag(P, dt, stem, 'f')
+            wp = self._w_fwd(dt, stem, cin_pad, max(64, cout), frag=frag)
             self._conv(dt, B[src].view(), dst_view if dst_view is not None else B[dst].view(), wp,
-                       self._bias([stem], max(64, cout)), 3, 3, 1, cin_pad, max(64, cout), RELU, alg_ci=cin)
+                       self._bias([stem], max(64, cout)), 3, 3, 1, cin_pad, max(64, cout),
+                       RELU | (_lib.CONV_WFRAG if frag else 0), alg_ci=cin)
 
         conv3('conv1_1_1', 'x0', 'a11', 3, 64)
         conv3('conv1_2_1', 'a11', 'a12', 64, 64)
@@ -422,8 +484,7 @@ class Engine:
             P.drop_hash = P.drop_active and self.net.dropout_masks is None
             if P.drop_hash:
                 # keep bits come from a counter-based hash of (seed, pixel, channel): nothing to store or re-read
-                self._seed = (getattr(self, '_seed', 0x5eed) * 1664525 + 1013904223) & 0xffffffff
-                P.drop_seed = self._seed
+                P.drop_seed = self._next_drop_seed()
                 epi |= _lib.EPI_DROPHASH
             elif P.drop_active:
                 dm = self._fill_dropout(P, heads)       # injected masks (parity tests)
@@ -484,11 +545,12 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ backward
-    def _w_bwd(self, dt, stem, rows_pad, cin_pad):
+    def _w_bwd(self, dt, stem, rows_pad, cin_pad, frag=False):
         """dgrad weights: rows = input channels, K = [flipped tap][output channel]."""
         w = self._param(stem + '.weight')
-        return self._packed((stem, 1, dt),
-                            lambda old: self._pack(dt, 1, w, rows_pad, cin_pad, w.shape[2], w.shape[3], out=old),
+        mode = 5 if frag else 1
+        return self._packed((stem, mode, dt),
+                            lambda old: self._pack(dt, mode, w, rows_pad, cin_pad, w.shape[2], w.shape[3], out=old),
                             (w._version, w.data_ptr()))
 
     def _w_heads1_bwd(self, dt):
@@ -583,8 +645,9 @@ class Engine:
             on_side(run)
 
         def dgrad(stem, src, dst, kh, kw, cpad, rows_pad, cin_pad, gate=None, epi=0, dropmask=None):
-            wp = self._w_bwd(dt, stem, rows_pad, cin_pad)
-            e = epi | (_lib.EPI_GATE if gate is not None else 0)
+            frag = stem in _BWD_IO and kh == 3 and self._frag(P, dt, stem, 'b')
+            wp = self._w_bwd(dt, stem, rows_pad, cin_pad, frag=frag)
+            e = epi | (_lib.EPI_GATE if gate is not None else 0) | (_lib.CONV_WFRAG if frag else 0)
             self._conv(dt, src, dst, wp, None, kh, kw, cpad, cin_pad, rows_pad, e, gate=gate, dropmask=dropmask,
                        dm_ld=512 * nh)
 

@@ -63,8 +63,10 @@ enum dbx_epilogue {
     DBX_EPI_DROPMASK = 8,   /* * 2 * mask[m][co] (uint8 {0,1}, unframed [M][c]) -- nn.Dropout(0.5) with a caller-supplied mask */
     DBX_EPI_ACCUM    = 16,  /* y += result (dtype of y) */
     DBX_EPI_F32_NCHW = 32,  /* write fp32 NCHW [N][cv][Ho][Wo] (cv = y->c valid channels) instead of framed NHWC */
-    DBX_EPI_DROPHASH = 64   /* nn.Dropout(0.5) with the keep bit of element (m, co) = dbx_drop_keep(desc.drop_seed, m, co): no mask
+    DBX_EPI_DROPHASH = 64,  /* nn.Dropout(0.5) with the keep bit of element (m, co) = dbx_drop_keep(desc.drop_seed, m, co): no mask
                                buffer; dbx_head2_dgrad regenerates the same bits in backward */
+    DBX_CONV_WFRAG   = 128  /* not an epilogue: w_packed is in MFMA-fragment order (dbx_pack_weight modes 4/5), the layout
+                               dbx_conv_plan() asks for when it selects the register-streamed-weights kernel */
 };
 
 typedef struct dbx_conv_desc {
@@ -82,6 +84,18 @@ int64_t dbx_conv_packed_elems(const dbx_conv_desc* d);
 int dbx_conv_forward(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
                      const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int32_t dropmask_ld,
                      void* stream);
+/* Which kernel dbx_conv_forward would run for (d, x, y), and the weight layout it wants.  The caller packs the weights
+ * accordingly (w_frag != 0: dbx_pack_weight mode 4 (forward) / 5 (dgrad) and DBX_CONV_WFRAG in d->epilogue; else modes 0 / 1).
+ * `name` is the kernel family and tile as it appears in a rocprofv3 trace (bench.py labels its roofline with it). */
+enum dbx_conv_kernel { DBX_K_IGEMM = 1, DBX_K_DMA = 2, DBX_K_BAND = 3, DBX_K_C64 = 4, DBX_K_C8 = 5, DBX_K_WS = 6 };
+typedef struct dbx_conv_plan_t {
+    int32_t kernel;        /* dbx_conv_kernel */
+    int32_t tile_m, tile_n;
+    int32_t w_frag;        /* 1: fragment-order weights wanted */
+    char    name[64];
+} dbx_conv_plan_t;
+int dbx_conv_plan(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y, dbx_conv_plan_t* out);
+
 /* 1x1 GEMM (16-bit types) with a split destination: couts [0, split_c) go to y with d->epilogue / gate, couts
  * [split_c, split_c + y2->c) to y2 with epilogue2 (plain, GATE and/or ACCUM) / gate2.  split_c = y->c, a multiple of 256.
  * Used for the data gradient of the fusion concat (torch.cat, DenseBox.py:219): one pass over the 2048-channel hidden
@@ -93,13 +107,19 @@ int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x, const void
 /* fp32 OIHW [co][ci][kh][kw] -> packed compute-dtype weight.
  * mode 0: forward            wp[co][tap][ci]            = w[co][ci][tap]
  * mode 1: dgrad (transposed) wp[ci][taps-1-tap][co]     = w[co][ci][tap]   (rows = ci, "cin" = co)
+ * mode 4 / 5: the same two matrices in MFMA-fragment order for the register-streamed-weights 3x3 kernel (rows_pad a
+ *   multiple of 128, cin_pad of 64): element (row, tap = 3 ky + kx, k) at
+ *   [row / BN][ky * KC + k / 64][kx * 4 + (k % 64) / 16][(row % BN) / 32][32 * ((k % 16) / 8) + row % 32][k % 8],
+ *   BN = 256 if rows_pad % 256 == 0 else 128, KC = cin_pad / 64 -- one 1-KiB block is the A operand of one
+ *   v_mfma_f32_32x32x16 for all 64 lanes.  Same size as modes 0 / 1.
  * ci_off/ci_cnt select an input-channel slice (used to concatenate several heads' 1x1 weights). */
 int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw, int32_t co, int32_t ci, int32_t kh, int32_t kw,
                     void* w_packed, int32_t rows_pad, int32_t cin_pad, int32_t row_off, int32_t k_off, void* stream);
 
 /* All parameters in ONE launch (after an optimizer step).  `jobs` is a device array of
  *   struct { const float* src; void* dst; int32 co, ci, taps, mode; int64 ktot; int32 cin_pad, row_off, k_off; }
- * mode 0/1 as dbx_pack_weight, mode 2 = fp32 bias copy into dst[row_off ...] (co = length, ci = taps = 1). */
+ * mode 0/1/4/5 as dbx_pack_weight (4/5: ktot carries rows_pad), mode 2 = fp32 bias copy into dst[row_off ...]
+ * (co = length, ci = taps = 1). */
 int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, void* stream);
 
 /* heads: data gradient of the nh (<= 4) Conv1x1(512->k_h) layers behind Dropout in one rank-k streaming pass:

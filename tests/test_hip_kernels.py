@@ -20,7 +20,7 @@ def framed(x_nchw, pad, tdt):
     """NCHW fp32 -> zero-framed NHWC tensor (with zero guard bands) + the View."""
     n, c, h, w = x_nchw.shape
     hp, wp = h + 2 * pad, w + 2 * pad
-    guard = max(8 * wp, 576 + wp) * c
+    guard = max(8 * wp, 576 + 4 * wp) * c
     flat = torch.zeros(2 * guard + n * hp * wp * c, dtype=tdt, device='cuda')
     t = flat[guard:guard + n * hp * wp * c].view(n, hp, wp, c)
     t[:, pad:pad + h, pad:pad + w] = x_nchw.permute(0, 2, 3, 1).to(tdt)
@@ -183,3 +183,99 @@ def test_head2_wgrad_kernel(ks, dtn):
     check(L.dbx_head2_wgrad(dt, C.byref(dv), C.byref(hv), (C.c_int32 * nh)(*ks), nh, (C.c_void_p * nh)(*[t.data_ptr() for t in dws]),
                             (C.c_void_p * nh)(*[t.data_ptr() for t in dbs]), ptr(sc), stream_ptr()))
     assert all(torch.equal(a, b) for a, b in zip(dw0, dws))
+
+
+# ---------------------------------------------------------------- register-streamed-weights 3x3 kernel (conv3x3_ws.hpp)
+# (n, h, w, cin, cout): every case must be picked by dbx_conv_plan as DBX_K_WS -- wide layers with >= 192 tiles.
+# 30x30 (one frame row = one 32-pixel fragment), odd sizes (tiles and fragments straddle rows and images), 128 couts
+# (two wave rows, 512-pixel tiles), 7- and 8-fragment tiles in one launch, image seams inside tiles.
+WS_CASES = [(40, 30, 30, 256, 512), (20, 61, 53, 128, 256), (10, 120, 97, 128, 128), (33, 45, 45, 192, 256)]
+
+
+def _ws_desc(L, dt, xv, yv, cin, cout, epi):
+    d = ConvDesc(dt, 3, 3, 1, cin, cout, epi)
+    plan = _lib.ConvPlan()
+    check(L.dbx_conv_plan(C.byref(d), C.byref(xv), C.byref(yv), C.byref(plan)))
+    assert plan.kernel == _lib.K_WS and plan.w_frag == 1, (plan.kernel, plan.name)
+    assert plan.name.decode().startswith('conv3x3_ws_kernel<')
+    return ConvDesc(dt, 3, 3, 1, cin, cout, epi | _lib.CONV_WFRAG)
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', WS_CASES)
+def test_conv_ws_forward(case, dtn):
+    n, h, w, ci, co = case
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    g = torch.Generator(device='cpu').manual_seed(sum(case))
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (ci * 9)) ** 0.5).cuda()
+    b = torch.randn(co, generator=g).cuda()
+    ref = F.relu(F.conv2d(x.to(tdt).float(), wt.to(tdt).float(), b, padding=1))
+    fx, tx, xv = framed(x, 1, tdt)
+    fy, ty, yv = framed(torch.zeros(n, co, h, w), 1, tdt)
+    d = _ws_desc(L, dt, xv, yv, ci, co, _lib.EPI_BIAS | _lib.EPI_RELU)
+    check(L.dbx_conv_forward(C.byref(d), C.byref(xv), ptr(pack(L, dt, wt, ci, co, mode=4)), ptr(b), C.byref(yv), None, None, 0, stream_ptr()))
+    got = ty[:, 1:1 + h, 1:1 + w].permute(0, 3, 1, 2).float()
+    tol = (2e-2 if dtn == 'bf16' else 3e-3)
+    assert torch.allclose(got, ref, rtol=tol, atol=tol), (got - ref).abs().max().item()
+    assert float(ty[:, 0].abs().sum()) == 0 and float(ty[:, :, 0].abs().sum()) == 0
+    assert float(ty[:, -1].abs().sum()) == 0 and float(ty[:, :, -1].abs().sum()) == 0
+    # the band kernel on row-major weights computes the same sums in another order: equal up to output rounding
+    fy2, ty2, yv2 = framed(torch.zeros(n, co, h, w), 1, tdt)
+    d0 = ConvDesc(dt, 3, 3, 1, ci, co, _lib.EPI_BIAS | _lib.EPI_RELU)
+    check(L.dbx_conv_forward(C.byref(d0), C.byref(xv), ptr(pack(L, dt, wt, ci, co)), ptr(b), C.byref(yv2), None, None, 0, stream_ptr()))
+    assert (ty.float() - ty2.float()).abs().max().item() <= tol * (1.0 + ref.abs().max().item())
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+@pytest.mark.parametrize('case', [(40, 30, 30, 256, 512), (20, 60, 60, 128, 256)])
+def test_conv_ws_dgrad_gate_and_sliced_views(case, dtn):
+    """Data gradient through the ws kernel (pack mode 5, ReLU gate), written into a channel slice of a wider frame and read
+    from a channel slice (the fusion concat's conv3_4 slot): dx = conv_transpose(dz, w) * (gate > 0)."""
+    n, h, w, ci, co = case                      # forward layer ci -> co; the dgrad maps co -> ci channels
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    g = torch.Generator(device='cpu').manual_seed(sum(case) + 1)
+    dz = torch.randn(n, co, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * (2.0 / (co * 9)) ** 0.5).cuda()
+    gate = torch.randn(n, ci, h, w, generator=g).cuda()
+    ref = F.conv_transpose2d(dz.to(tdt).float(), wt.to(tdt).float(), padding=1) * (gate.to(tdt).float() > 0)
+    # dz lives in channels [64, 64 + co) of a wider frame; dx goes to channels [128, 128 + ci) of a 128 + ci + 64 wide frame
+    wide = torch.zeros(n, 64 + co + 64, h, w, device='cuda')
+    wide[:, 64:64 + co] = dz
+    fz, tz, zv_all = framed(wide, 1, tdt)
+    zv = View(zv_all.ptr, n, h, w, 1, zv_all.ld, 64, co)
+    fd, td, dv_all = framed(torch.zeros(n, 128 + ci + 64, h, w), 1, tdt)
+    dv = View(dv_all.ptr, n, h, w, 1, dv_all.ld, 128, ci)
+    fg, tg, gv = framed(gate, 1, tdt)
+    d = _ws_desc(L, dt, zv, dv, co, ci, _lib.EPI_GATE)
+    check(L.dbx_conv_forward(C.byref(d), C.byref(zv), ptr(pack(L, dt, wt, co, ci, mode=5)), None, C.byref(dv), C.byref(gv), None, 0,
+                             stream_ptr()))
+    got = td[:, 1:1 + h, 1:1 + w, 128:128 + ci].permute(0, 3, 1, 2).float()
+    tol = (2e-2 if dtn == 'bf16' else 3e-3)
+    assert torch.allclose(got, ref, rtol=tol, atol=tol), (got - ref).abs().max().item()
+    assert float(td[..., :128].abs().sum()) == 0 and float(td[..., 128 + ci:].abs().sum()) == 0     # neighbours untouched
+    assert float(td[:, 0].abs().sum()) == 0 and float(td[:, :, -1].abs().sum()) == 0                # frame untouched
+
+
+def test_pack_fragment_order_matches_documented_index():
+    """dbx_pack_weight modes 4/5 against the index formula of include/densebox_hip.h, built with numpy."""
+    L = _lib.lib()
+    dt = _lib.DTYPE_ID['f16']
+    for co, ci, mode in [(256, 128, 4), (128, 192, 4), (256, 128, 5), (128, 256, 5)]:
+        g = torch.Generator(device='cpu').manual_seed(co + ci + mode)
+        wt = torch.randn(co, ci, 3, 3, generator=g)
+        rows, k = (co, ci) if mode == 4 else (ci, co)
+        got = pack(L, dt, wt.cuda(), k, rows, mode=mode).view(torch.float16).cpu().numpy()
+        w16 = wt.to(torch.float16).numpy().reshape(co, ci, 9)
+        bn = 256 if rows % 256 == 0 else 128
+        kc = k // 64
+        exp = np.zeros(rows * 9 * k, dtype=np.float16)
+        r_, t_, k_ = np.meshgrid(np.arange(rows), np.arange(9), np.arange(k), indexing='ij')
+        ky, kx = t_ // 3, t_ % 3
+        blk = ((((r_ // bn) * (3 * kc) + ky * kc + k_ // 64) * 12 + kx * 4 + (k_ % 64) // 16) * (bn // 32) + (r_ % bn) // 32)
+        idx = (blk * 64 + 32 * ((k_ % 16) // 8) + r_ % 32) * 8 + k_ % 8
+        src = w16[r_, k_, t_] if mode == 4 else w16[k_, r_, 8 - t_]
+        exp[idx.ravel()] = src.ravel()
+        assert np.array_equal(got[:exp.size], exp), (co, ci, mode)
