@@ -5,7 +5,8 @@ A "step" = one full training step of the reference loop body (DenseBox.py:2016-2
 240x240 patches already resident in HBM: forward, fused dense loss with hard-negative mining, backward,
 gradient all-reduce over RCCL (N>1), fused SGD.  Workload = BASELINE.json configs[2]/[3]: DenseBoxLMLOC (the net
 the reference's __main__ trains: score + bbox + landmark heat-maps + landmark offsets + refine), batch 64 per GPU,
-bf16 compute / fp32 accumulate / fp32 master weights.  Weak scaling: per-GPU batch fixed.
+f16 compute (--dtype bf16 for configs[3]'s type; same MFMA rate) / fp32 accumulate / fp32 master weights.  Weak scaling:
+per-GPU batch fixed.  The line also carries the bf16 step rate (`bf16`) and the inference half of the metric (`inference`).
 
   python bench.py --gpus 1 --steps 20 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -13,6 +14,7 @@ bf16 compute / fp32 accumulate / fp32 master weights.  Weak scaling: per-GPU bat
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -79,21 +81,75 @@ def cpu_baseline(kind, seconds=20.0):
                       % (it, n, kind, el)}
 
 
+def csrc_hash():
+    """Hash of the kernel sources: a PMC summary is only quoted for the kernels it was measured on."""
+    import hashlib
+    d = os.path.join(ROOT, 'densebox_amd', 'csrc')
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.hpp')):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:12]
+
+
 def pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed PMC summary (profiles/r01_pmc_traffic.json: separate
+    """HBM bytes per launch of a kernel family from the committed PMC summary (profiles/r02_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH_SIZE doubled per the gfx950 correction
-    in MI355X_MICROARCH.md; tools/pmc_traffic.py).  None when the summary or the family is absent."""
-    import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    m = re.match(r'(\w+)<(\w+)((?:,\d+)*)', family)
-    if not m or not os.path.exists(path):
+    in MI355X_MICROARCH.md; tools/pmc_traffic.py stamps it with csrc_hash()).  None when the summary is absent, was
+    collected on other kernel sources, or does not list the family."""
+    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    doc = json.load(open(path))
+    if doc.get('csrc_hash') != csrc_hash():
+        return None
+    # rocprof names are mangled: match on the family name and its template integers
+    m = re.match(r'(\w+)<(\w+)((?:,\d+)*)>', family)
+    if not m:
         return None
     code = {'bf16': 'DF16b', 'f16': 'DF16_', 'f32': 'f'}[m.group(2)]
-    key = '%sI%s%s' % (m.group(1), code, ''.join('Li%sE' % v for v in m.group(3).split(',') if v))
-    for k, v in json.load(open(path)).items():
-        if key in k:
+    ints = [v for v in m.group(3).split(',') if v]
+    for k, v in doc.get('kernels', {}).items():
+        if m.group(1) in k and ('I' + code) in k and all(('Li%sE' % i) in k for i in ints[-1:]):
             return round(v['hbm_bytes_per_launch'])
     return None
+
+
+def inference(kind, dev):
+    """Second half of BASELINE.json's metric: whole-image forward + on-GPU top-10 decode + NMS, one image at a time (the
+    reference test drivers, DenseBox.py:3772-3799), results on the host.  f16, eval mode (folded heads, hipGraph replay)."""
+    net = getattr(D, kind)(synth.vgg19_standin(seed=0))
+    synth.fill_params_(net, 11)
+    net = net.to(dev).eval()
+    net.compute_dtype = 'f16'
+    res = {}
+    for name, (h, w, K) in (('512x512', (512, 512, 10)), ('1920x1080', (1080, 1920, 10)), ('1920x1080_top1000', (1080, 1920, 1000))):
+        x = synth.synth_images(1, h, w, seed=1).to(dev)
+        for _ in range(3):
+            net.detect(x, K=K, nms_thresh=0.4)
+        torch.cuda.synchronize()
+        it = 30 if h <= 512 else 15
+        t0 = time.perf_counter()
+        for _ in range(it):
+            dets, keep = net.detect(x, K=K, nms_thresh=0.4)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / it
+        res[name] = {'img_per_s': round(1.0 / dt, 1), 'ms': round(dt * 1e3, 3), 'topk': K,
+                     'tflops': round(FWD_GFLOP[kind] * h * w / (240.0 * 240.0) / dt / 1e3, 1)}
+    return {'metric': 'inference fps (forward + top-K + NMS, one image, results on host)', 'net': kind, 'dtype': 'f16',
+            'value': res['512x512']['img_per_s'], 'unit': 'img/s at 512x512', 'sizes': res}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def measured_peaks(dev, dtype):
@@ -126,14 +182,30 @@ def main():
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--kind', default='DenseBoxLMLOC', choices=list(FWD_GFLOP))
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f16', 'f32'])
+    ap.add_argument('--dtype', default='f16', choices=['bf16', 'f16', 'f32'],
+                    help='compute dtype; f16 = BASELINE configs[1]/[2] and 10x closer to the reference than bf16 (profiles/r02_lowprec_errors.json)')
     ap.add_argument('--batch', type=int, default=64, help='patches per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--no-inference', action='store_true')
+    ap.add_argument('--dry-run', action='store_true', help='launcher / rendezvous only: no GPU work (CPU test of the N>1 launch path)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))            # one rank per GPU; rank 0 of the child job prints the JSON line
     rank, world, local = init_from_env()
-    assert world == args.gpus or world == 1, 'launch with torchrun --nproc-per-node == --gpus'
+    assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
+    if args.dry_run:
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({'metric': 'training patches/sec (240x240)', 'dry_run': True, 'n_gpus': world,
+                              'rank_sum': int(t.item()), 'backend': dist.get_backend() if world > 1 else None}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     local = local % torch.cuda.device_count()          # (several ranks may share a GPU under DBX_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
@@ -151,11 +223,15 @@ def main():
     x = x.to(dev)
     rs = np.random.RandomState(1234 + rank)
     use_lab = lab if kind == 'DenseBoxLMLOC' else None
-    p_global = dp.global_positive_num(bbox, use_lab)                           # fixed labels -> fixed global count
-    _, half = LB.neg_counts(p_global, n * world)
+    half = 0
 
     def one_step():
-        # host RNG draws of the reference loop (DenseBox.py:2089-2094, :2133-2138) stay inside the step
+        # everything the reference loop body does per iteration stays inside the step: the global positive count
+        # (DenseBox.py:2070-2074; host loop over the boxes + one int64 all-reduce on the gloo side group) and the host RNG
+        # draws (DenseBox.py:2089-2094, :2133-2138)
+        nonlocal half
+        p_global = dp.global_positive_num(bbox, use_lab)
+        _, half = LB.neg_counts(p_global, n * world)
         rn = np.stack([rs.choice(3600, half, replace=False) for _ in range(n)]) if half else np.zeros((n, 0), np.int64)
         lrn = rs.randint(0, 3600, size=(4, n, 1)) if kind != 'DenseBox' else None
         return dp.step(x, bbox, vert, lab, rand_neg_indices=rn, lm_rand_neg_indices=lrn, positive_num_global=p_global)
@@ -224,6 +300,25 @@ def main():
         mp = measured_peaks(dev, args.dtype)
         roof['measured_peak'] = mp
         roof['frac_of_measured_gemm'] = round(ach / mp['library_gemm_8192_tflops'], 4)
+        out['roofline']['traffic_source'] = 'profiles/r02_pmc_traffic.json (null unless collected on these kernel sources)'
+    # the other 16-bit type on the same workload (configs[3] names bf16): a short secondary measurement, every rank takes part
+    other = {'f16': 'bf16', 'bf16': 'f16'}.get(args.dtype)
+    if other and not args.no_inference:
+        net.compute_dtype = other
+        for _ in range(3):
+            one_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            one_step()
+        barrier()
+        dt2 = time.perf_counter() - t1
+        net.compute_dtype = args.dtype
+        if rank == 0:
+            out[other] = {'value': round(n * world * 10 / dt2, 1), 'unit': 'patches/s', 'ms_per_step': round(dt2 / 10 * 1e3, 3), 'steps': 10}
+    if rank == 0:
+        if not args.no_inference:
+            out['inference'] = inference(kind, dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(kind, args.cpu_seconds)
     barrier()

@@ -682,8 +682,8 @@ __global__ void pack_multi_kernel(const PackJob* __restrict__ jobs) {
         T* wp = (T*)j.dst;
         if (j.mode == 0) wp[(long long)(j.row_off + o) * j.ktot + (long long)t * j.cin_pad + j.k_off + c] = from_f32<T>(v);
         else if (j.mode == 1) wp[(long long)(j.row_off + c) * j.ktot + (long long)(j.taps - 1 - t) * j.cin_pad + j.k_off + o] = from_f32<T>(v);
-        else if (j.mode == 4) wp[dbx_frag_index(j.row_off + o, t, j.k_off + c, j.cin_pad, (int)j.ktot)] = from_f32<T>(v);
-        else wp[dbx_frag_index(j.row_off + c, j.taps - 1 - t, j.k_off + o, j.cin_pad, (int)j.ktot)] = from_f32<T>(v);
+        else if (j.mode == 4) wp[dbx_frag_index(j.row_off + o, t, j.k_off + c, j.cin_pad, (int)j.ktot, j.taps)] = from_f32<T>(v);
+        else wp[dbx_frag_index(j.row_off + c, j.taps - 1 - t, j.k_off + o, j.cin_pad, (int)j.ktot, j.taps)] = from_f32<T>(v);
     }
 }
 template <typename T> static int pack_multi_t(const void* jobs, int count, long long max_elems, hipStream_t s) {

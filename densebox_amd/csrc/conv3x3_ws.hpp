@@ -1,5 +1,5 @@
 // v7: 3x3 / pad-1 convolution with register-streamed weights ("ws"): four fat waves (one per SIMD, the whole 512-register
-// file each), persistent workgroups.  Included by conv_igemm.hip (needs ConvArgs, gate_packed16, Mma32 / pipe::IC).
+// file each), persistent workgroups.  Included by conv_igemm.hip (needs ConvArgs, gate_packed16).
 // Forward and -- with flipped/transposed weights -- dgrad of every wide backbone layer (16-bit types).
 //
 // Measured background (tools/band_lab.hip on MI355X, conv4_2 at batch 64, uniform random operands): the 8-wave LDS kernels
@@ -27,35 +27,54 @@
 //   compiler-scheduled epilogue (vmcnt(0) on both sides).
 #pragma once
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T> struct Mma32;
+template <> struct Mma32<_Float16> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma32<__bf16> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+namespace pipe { template <int N> struct IC { static constexpr int value = N; }; }   // compile-time step indices for generic lambdas
+
+
 namespace ws {
 constexpr int D = 2;                            // weight loads run D steps ahead
-constexpr int NSTEP = 12;                       // K=16 steps per period: kx * 4 + 16-channel chunk
 constexpr int WL = 2;                           // weight loads per wave and step (64 couts = two 32-row fragments)
-// band pieces (8 rows x 128 B) per period for WM wave rows of 256 pixels, and per-wave LDS-DMA slots (4 waves)
-constexpr int pieces(int WM) { return (256 * WM + 2 + 7) / 8; }
-constexpr int slots(int WM) { return (pieces(WM) + 3) / 4; }
-// LDS-DMA loads a wave issues at step i of a period (behind the step's weight loads): the next period's band
-// -- only in steps 0 .. NSTEP-D-2: the seam wait at step NSTEP-1 (for the weights issued at step NSTEP-1-D) must cover them all
-constexpr int g(int i, int WM) {
-    constexpr int NA = NSTEP - D - 1;                                   // 9 issue steps
-    if (i < 0 || i >= NA) return 0;
-    const int s = slots(WM), lo = s / NA, rem = s % NA;                // WM 1: 9 = one per step; WM 2: 17 = 2 in steps 0..7, 1 in step 8
+// K=16 steps per period.  3x3: period = (ky, 64-channel chunk), step = kx * 4 + 16-channel chunk, ONE band of 128-byte rows read at
+// row shifts 0/1/2.  1x1: period = 128 channels, step = sub-band * 4 + 16-channel chunk, TWO sub-bands of 128-byte rows.
+constexpr int nstep(int KS) { return KS == 3 ? 12 : 8; }
+constexpr int subs(int KS) { return KS == 3 ? 1 : 2; }
+// band pieces (8 rows x 128 B) per sub-band for WM wave rows of 256 pixels, per period, and per-wave LDS-DMA slots (4 waves)
+constexpr int sub_pieces(int WM, int KS) { return (256 * WM + (KS == 3 ? 2 : 0) + 7) / 8; }
+constexpr int pieces(int WM, int KS) { return subs(KS) * sub_pieces(WM, KS); }
+constexpr int slots(int WM, int KS) { return (pieces(WM, KS) + 3) / 4; }
+// LDS-DMA loads a wave issues at step i of a period (behind the step's weight loads): the next period's band -- only in
+// steps 0 .. NS-D-2: the seam wait at step NS-1 (for the weights issued at step NS-1-D) must cover them all
+constexpr int g(int i, int WM, int KS) {
+    const int NS = nstep(KS), NA = NS - D - 1;                          // 9 (3x3) / 5 (1x1) issue steps
+    i = ((i % NS) + NS) % NS;
+    if (i >= NA) return 0;
+    const int s = slots(WM, KS), lo = s / NA, rem = s % NA;            // 3x3: 9 = 1 per step (WM 1), 17 = 2,..,2,1 (WM 2); 1x1: 16 = 4,3,3,3,3
     return lo + (i < rem ? 1 : 0);
 }
-constexpr int gsum(int i, int WM) { int n = 0; for (int k = 0; k < i; ++k) n += g(k, WM); return n; }   // slots before step i
+constexpr int gsum(int i, int WM, int KS) { int n = 0; for (int k = 0; k < i; ++k) n += g(k, WM, KS); return n; }   // slots before step i
 // VMEM operations issued after the weight loads of step j (which go out at step j - D): may still be in flight at its wait.
-// Steps before 0 belong to the previous period (same schedule) -- or to the tile start, where everything was drained.
-// The last period of a tile issues no weight loads in its last D steps (the next tile starts its own stream).
-constexpr int allowed(int j, int WM, bool first, bool last) {
+// (A tile's last period issues a few extra LDS-DMA pieces in its last D steps and older stores may be pending at a tile
+// start: both only make a wait longer.)
+constexpr int allowed(int j, int WM, int KS) {
     int n = 0;
-    for (int i = j - D; i <= j - 1; ++i) {
-        const bool prev = i < 0;
-        if (prev && first) continue;
-        const int ii = prev ? i + NSTEP : i;
-        n += g(ii, WM) + ((i > j - D && !(last && !prev && i >= NSTEP - D)) ? WL : 0);
-    }
+    for (int i = j - D; i <= j - 1; ++i) n += g(i, WM, KS) + (i > j - D ? WL : 0);
     return n;
 }
+constexpr int wld(int WM) { return 2 / WM; }                            // LDS-DMA pieces per wave for one weight step: 8 KB (BN 256) / 4 KB (BN 128)
+constexpr int gmax(int WM, int KS) { int m = 0; for (int i = 0; i < nstep(KS); ++i) m = g(i, WM, KS) > m ? g(i, WM, KS) : m; return m; }
 }  // namespace ws
 
 struct WsArgs {
@@ -64,17 +83,22 @@ struct WsArgs {
     int items;           // mt * ntile_n work items
     int hwp;             // H * Wp: q' per image
     int qtot;            // N * H * Wp
+    int xpad;            // frame width of x (1; 0 for an unframed 1x1 input): halo columns fx < xpad, fx >= Wp - xpad are dropped
+    int dbg;             // DBX_WS_DBG (development): 1 no periods, 2 no stores, 4 no band DMA, 8 no weight loads
 };
 
-template <typename T, int WM>
+template <typename T, int WM, int KS>
 __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const WsArgs t) {
     using namespace ws;
     constexpr int ES = sizeof(T);
     static_assert(ES == 2, "16-bit types");
+    static_assert(KS == 3 || (KS == 1 && WM == 1), "3x3, or 1x1 with 256-cout tiles");
     constexpr int WN = 4 / WM;                                          // waves along the couts
     constexpr int BN = 64 * WN;
-    constexpr int AP = pieces(WM), SL = slots(WM), ABUF = AP * 1024;
+    constexpr int NSTEP = nstep(KS), SUBS = subs(KS), PS = sub_pieces(WM, KS);
+    constexpr int AP = pieces(WM, KS), SL = slots(WM, KS), ABUF = AP * 1024, SUBB = PS * 1024;
     constexpr int WSTEP = BN * 32;                                      // packed weight bytes per step of one BN-cout tile
+    constexpr int WLZ = 2 * ABUF;                                       // LDS landing zone of a tile's first D weight steps
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -82,19 +106,30 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, h = lane >> 5;
     const int pix_bytes = a.x_ld * ES;
-    const int cin_bytes = a.cpt * 16;
-    const int KC = cin_bytes / 128;                                    // 64-channel chunks
-    const int P = 3 * KC;                                              // periods
-    const int epi = a.epi;
+    const int KC = a.cpt / 8;                                           // 64-channel chunks
+    const int P = KS == 3 ? 3 * KC : KC / 2;                            // periods
     const int wp = a.x_wp;
 
-    // ---- persistent schedule: workgroup g runs on XCD g % 8; item = round * G + (xcd-contiguous index), so the 32 workgroups of
-    // an XCD work on 32 consecutive items (both cout tiles of 16 neighbouring pixel tiles) at any time
+    // ---- persistent schedule: workgroup g runs on XCD g % 8.  One cout tile: item = round * G + (xcd-contiguous index), so the 32
+    // workgroups of an XCD work on 32 neighbouring pixel tiles at any time.  Two or four cout tiles (conv4: 512 couts): an XCD
+    // keeps to ONE of them for the whole launch -- its workgroups stream the same 2.4 MB of weights, which then stay in its
+    // 4 MB L2 (both halves together thrash it, and L2 misses are capped at ~12 B/clk/CU against 16 B/clk/CU of demand);
+    // the pixel bands are then fetched by two XCDs instead of one (5 B/clk/CU).
     const int G = gridDim.x;
-    int item = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const bool by_xcd = (G & 7) == 0 && (a.ntile_n == 2 || a.ntile_n == 4);
+    int item, istride;                                                  // linear (tile_m, tile_n) index: tm * ntile_n + tn
+    if (by_xcd) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        item = ((xcd / a.ntile_n) * (G >> 3) + j) * a.ntile_n + xcd % a.ntile_n;
+        istride = G;                                                    // G / ntile_n pixel tiles per round
+    } else {
+        item = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+        istride = G;
+    }
+    if (item >= t.items) return;
 
-    // ---- per-tile state
-    struct Tile { int q0, nf, n0, sw; const char* wbase; long long src0; };
+    // ---- per-tile state (all uniform)
+    struct Tile { int q0, nf, n0, sw; const char* wbase; const char* abase; };
     auto tile_of = [&](int it) {
         Tile r;
         const int tm = it / a.ntile_n, tn = it - tm * a.ntile_n;
@@ -103,21 +138,23 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
         r.q0 = u0 * (32 * WM);
         r.n0 = tn * BN;
         const int img = r.q0 / t.hwp;
-        // first band row that belongs to the next image: pixel index of its first q' in this tile, + 1 (see header)
-        r.sw = (img + 1) * t.hwp - r.q0 + 1;
+        // first band row that belongs to the next image: pixel index of its first q' in this tile (+ 1 for 3x3, see header)
+        r.sw = (img + 1) * t.hwp - r.q0 + (KS == 3 ? 1 : 0);
         r.wbase = a.w + (size_t)tn * P * NSTEP * WSTEP;
-        // frame position of band row 0 for ky = 0: pos(q0) - 1 - Wp, pos(q') = q' + (2 img + 1) Wp
-        r.src0 = (long long)r.q0 + (long long)(2 * img + 1) * wp - 1 - wp;
+        // band row 0 is frame position pos(q0) (3x3, ky = 0: - 1 - Wp), pos(q') = q' + (2 img + 1) Wp xpad
+        r.abase = a.x + ((long long)r.q0 + (long long)(2 * img + 1) * wp * t.xpad - (KS == 3 ? 1 + wp : 0)) * pix_bytes;
         return r;
     };
 
     // ---- weight stream: scalar base walks the packed image step by step, one lane offset for the whole kernel
     const unsigned wvoff = wn * 2048 + lane * 16;
     const char* wptr;
-    u32x4 wr[D + 1][2];
+    constexpr int RING = KS == 3 ? D + 1 : D + 2;                       // weight register sets: divides NSTEP (12 / 8)
+    static_assert(NSTEP % RING == 0 && RING > D, "weight ring");
+    u32x4 wr[RING][2];
+    // s_nop 4: the base may have just been restored from a spill by v_readlane (VALU-written SGPR -> VMEM address needs five
+    // wait states; the compiler pads its own instructions, not the inside of an asm statement)
     auto wload = [&](int set) {
-        // s_nop 4: the base may have just been restored from a spill by v_readlane (VALU-written SGPR -> VMEM address needs five
-        // wait states; the compiler pads its own instructions, not the inside of an asm statement)
         asm volatile("s_nop 4\n\t"
                      "global_load_dwordx4 %0, %2, %3\n\t"
                      "global_load_dwordx4 %1, %2, %3 offset:1024"
@@ -129,52 +166,69 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
 
     // ---- band pieces by LDS-DMA: slot i of this wave is piece wave + 4 i; slots past the last piece repeat the wave's last real
     // piece (same bytes to the same place) so that every wave issues the same number of loads (uniform counted waits).
-    // The chunk swizzle goes on the source address: chunk ^ ((row >> 1) & 7), row = 8 (wave + 4 i) + lr8.
-    // Address = uniform 64-bit base of the piece (scalar arithmetic) + one 32-bit lane offset; the halo-row skip is a per-lane
-    // select.  (Per-slot 64-bit lane pointers would be loop invariants the compiler keeps -- and spills.)
+    // Address = uniform base of the piece (scalar arithmetic) + ONE lane offset register; the halo-row skip is a per-lane select
+    // against a uniform threshold.  The chunk swizzle goes on the source: chunk ^ ((row >> 1) & 7), row = 8 (wave + 4 i) + lr8.
     const int lr8 = lane >> 3, lc8 = lane & 7;
     const unsigned a_lane = lr8 * pix_bytes + ((lc8 ^ ((4 * wave + (lr8 >> 1)) & 7)) << 4);
-    const unsigned skip_bytes = 2 * wp * pix_bytes;
-    auto issue_a = [&](const Tile& tl, int ab, int buf, int i) {
+    const unsigned skip_bytes = 2 * wp * t.xpad * pix_bytes;
+    auto issue_a = [&](const char* abase, int sw, int ab, int buf, int i) {
         int ii = i;
         if (wave + 4 * i >= AP) ii = i - 1;                             // uniform per wave
-        const int row0 = 8 * (wave + 4 * ii);                           // uniform
-        const char* sbase = a.x + (tl.src0 + row0) * (long long)pix_bytes + ab;
-        const unsigned voff = a_lane + ((row0 + lr8 >= tl.sw) ? skip_bytes : 0u);
+        const int piece = wave + 4 * ii;
+        const int sub = SUBS == 1 ? 0 : piece / PS;                     // 1x1: second 64-channel chunk of the period
+        const int row0 = 8 * (piece - sub * PS);                        // uniform
+        const char* sbase = abase + row0 * pix_bytes + ab + sub * 128;
+        const unsigned voff = a_lane + ((lr8 >= sw - row0) ? skip_bytes : 0u);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sbase + voff),
                                          (__attribute__((address_space(3))) void*)(smem + buf * ABUF + (wave + 4 * ii) * 1024), 16, 0, 0);
+    };
+    // first D weight steps of a tile by LDS-DMA into the landing zone: piece p of step d = bytes [1024 p, +1024) of that step
+    auto issue_w0 = [&](const char* wbase, int d) {
+#pragma unroll
+        for (int i = 0; i < wld(WM); ++i) {
+            const int p = wave * wld(WM) + i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + d * WSTEP + p * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(smem + WLZ + d * WSTEP + p * 1024), 16, 0, 0);
+        }
     };
 
     // ---- fragment read addresses: 128-byte rows, chunk 2 c + h of row l31 + kx (+ 32 mi), swizzle (row >> 1) & 7
     int xlane[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) xlane[kx] = (l31 + kx) * 128 + ((h ^ (((l31 + kx) >> 1) & 7)) << 4);   // + wave row: 32 NF wm rows
+    // step j of a period reads chunk pair j % 4 at row shift j / 4 (3x3) or of sub-band j / 4 (1x1)
+    auto xoff = [&](int j, int xb0) { return KS == 3 ? (xb0 ^ ((j & 3) << 5)) : (j >> 2) * SUBB + (xb0 ^ ((j & 3) << 5)); };
 
     u32x4 xf[2][8];
     int buf = 0;
-    if (item >= t.items) return;
     Tile cur = tile_of(item);
 
-    // ---- prologue of the first tile: its first band (the later tiles' first bands are issued by their predecessors)
+    // ---- prologue of the first tile: its first band and weight steps (the later tiles' are issued by their predecessors)
 #pragma unroll
-    for (int i = 0; i < SL; ++i) issue_a(cur, 0, 0, i);
+    for (int i = 0; i < SL; ++i) issue_a(cur.abase, cur.sw, 0, 0, i);
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue_w0(cur.wbase, d);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     for (;;) {
-        const int nxt_item = item + G;
-        const Tile nxt = tile_of(nxt_item < t.items ? nxt_item : item);     // last tile: a harmless re-fetch of its own start
-        // ---- tile start: band 0 has been issued (prologue or the previous tile's last period: LDS-DMA involves no registers, so it
-        // may fly across the compiler-scheduled epilogue).  The first D weight steps are fetched HERE, behind the epilogue's
-        // stores, and waited for at once: an asm load whose destination the compiler believes to be ready must not be in
-        // flight across code that may spill or move it.
-        wptr = cur.wbase;
-#pragma unroll
-        for (int d = 0; d < D; ++d) wload(d);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- tile start: band 0 and the first D weight steps sit in the LDS (every wave waited for its own pieces: prologue, or
+        // the vmcnt(0) in front of the previous epilogue -- LDS-DMA involves no registers, so it may fly across compiler-
+        // scheduled code, unlike an asm load whose destination the compiler believes to be ready and may spill or move).
+        // The epilogue's stores may still be in flight: they only make the first counted waits of the tile wait longer.
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        wptr = cur.wbase + D * WSTEP;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            wr[d][0] = *(const u32x4*)(smem + WLZ + d * WSTEP + wvoff);
+            wr[d][1] = *(const u32x4*)(smem + WLZ + d * WSTEP + wvoff + 1024);
+        }
+        const int nxt_item = item + istride;
+        const bool more = nxt_item < t.items;
+        Tile nxt = cur;                                                 // last tile: a harmless re-fetch of its own start
 
         // One tile, specialised on its fragment count.  The accumulators live and die inside: the two instantiations assign them
-        // to different registers, and nothing but scalars and the prefetched operands crosses the merge behind the branch.
+        // to different registers, and nothing but scalars and the operand fragments crosses the merge behind the branch.
         auto body = [&](auto NF_) {
             constexpr int NF = decltype(NF_)::value;
             constexpr int NM = 2 * NF;                                  // MFMAs per step
@@ -187,90 +241,109 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                     for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.f;
             const int xrow = wm * NF * 32 * 128;                        // this wave row's first band row (bytes)
             {
-                const char* xp = smem + buf * ABUF + xrow + xlane[0];
+                const char* xp = smem + buf * ABUF + xrow + xoff(0, xlane[0]);
 #pragma unroll
                 for (int mi = 0; mi < NF; ++mi) xf[0][mi] = *(const u32x4*)(xp + mi * 4096);
             }
             int p_ky = 0, p_kc = 0;
-            // FIRST: nothing was in flight at the tile start; LAST: the band / weights issued are the next tile's
-            auto period = [&](auto FIRST_, auto LAST_) {
-                constexpr bool FIRST = decltype(FIRST_)::value != 0, LAST = decltype(LAST_)::value != 0;
+            // ONE period body for every period of the tile (a FIRST / LAST specialisation triples the code and the register
+            // pressure: the compiler then spills lane invariants and drains the pipeline around every reload).  What differs is
+            // scalar: whose band is prefetched, two skipped waits at the tile start, extra LDS-DMA at the tile end.
+            for (int m = 0; m < ((t.dbg & 1) ? 0 : P); ++m) {
+                const bool first = m == 0, last = m == P - 1;
+                if (last && more) nxt = tile_of(nxt_item);
                 int ab_nxt = 0;
-                if (!LAST) {
-                    if (++p_kc == KC) { p_kc = 0; ++p_ky; }
-                    ab_nxt = p_ky * wp * pix_bytes + p_kc * 128;
+                if (!last) {
+                    if (KS == 3) {
+                        if (++p_kc == KC) { p_kc = 0; ++p_ky; }
+                        ab_nxt = p_ky * wp * pix_bytes + p_kc * 128;
+                    } else {
+                        ab_nxt = (m + 1) * 256;
+                    }
                 }
-                const Tile& atile = LAST ? nxt : cur;
+                const char* asrc = last ? nxt.abase : cur.abase;
+                const int asw = last ? nxt.sw : cur.sw;
                 auto step = [&](auto J_) {
                     constexpr int j = decltype(J_)::value;
-                    constexpr int wsx = j % (D + 1), wnx = (j + D) % (D + 1), xs = j & 1;
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allowed(j, WM, FIRST, LAST)) : "memory");
-                    if (j == NSTEP - 1 && !LAST) {
+                    constexpr int wsx = j % RING, wnx = (j + D) % RING, xs = j & 1;
+                    // the weights of steps 0 .. D-1 of a tile came through the LDS: nothing to wait for
+                    if (j >= D || !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allowed(j, WM, KS)) : "memory");
+                    if (j == NSTEP - 1) {
                         // period seam: the next band landed (its loads are older than the weights just waited for) and every
-                        // wave is done with this one (its last reads were issued a step ago)
+                        // wave is done with this one (its last reads were issued a step ago).  In a tile's last period this
+                        // publishes nothing yet (the next tile's band is waited for in front of the epilogue): harmless.
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    constexpr bool rd = !(LAST && j == NSTEP - 1);
                     const int rbuf = j == NSTEP - 1 ? buf ^ 1 : buf;
                     constexpr int jn = (j + 1) % NSTEP;
-                    int xb = xlane[jn >> 2];
+                    int xb = xlane[KS == 3 ? jn >> 2 : 0];
                     asm volatile("" : "+v"(xb));                        // recompute per step: twelve hoisted address registers spill
-                    const char* xp = smem + rbuf * ABUF + xrow + (xb ^ ((jn & 3) << 5));
-                    constexpr int GA = g(j, WM), G0 = gsum(j, WM);
+                    const char* xp = smem + rbuf * ABUF + xrow + xoff(jn, xb);
+                    constexpr int GA = g(j, WM, KS), G0 = gsum(j, WM, KS);
 #pragma unroll
                     for (int k = 0; k < NM; ++k) {
                         Mma32<T>::run(wr[wsx][k / NF], xf[xs][k % NF], acc[k / NF][k % NF]);
-                        if (rd && k < NF) xf[xs ^ 1][k] = *(const u32x4*)(xp + k * 4096);
-                        if (k == NF + 1 && !(LAST && j >= NSTEP - D)) wload(wnx);
-                        if (k == NF + 3 && GA > 0) issue_a(atile, ab_nxt, buf ^ 1, G0);
-                        if (k == NF + 5 && GA > 1) issue_a(atile, ab_nxt, buf ^ 1, G0 + 1);
+                        // (not in a tile's very last step: its band is the next tile's, still landing -- the tile start reads it)
+                        if (k < NF && !(last && j == NSTEP - 1)) xf[xs ^ 1][k] = *(const u32x4*)(xp + k * 4096);
+                        if (k == NF + 1 && !(t.dbg & 8)) wload(wnx);    // (a tile's last D steps run past its stream: drained, unused)
+                        if (k == NF + 3 && GA > 0 && !(t.dbg & 4)) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0);
+                        if (k == NF + 5 && GA > 1) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 1);
+                        if (k == NF + 6 && GA > 2) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 2);
+                        if (k == NM - 1 && GA > 3) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 3);
+                        if (k == NF + 3 && j >= NSTEP - D && last) issue_w0(nxt.wbase, j - (NSTEP - D));
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
                 step(pipe::IC<0>{}); step(pipe::IC<1>{}); step(pipe::IC<2>{}); step(pipe::IC<3>{}); step(pipe::IC<4>{}); step(pipe::IC<5>{});
-                step(pipe::IC<6>{}); step(pipe::IC<7>{}); step(pipe::IC<8>{}); step(pipe::IC<9>{}); step(pipe::IC<10>{}); step(pipe::IC<11>{});
+                step(pipe::IC<6>{}); step(pipe::IC<7>{});
+                if constexpr (KS == 3) { step(pipe::IC<8>{}); step(pipe::IC<9>{}); step(pipe::IC<10>{}); step(pipe::IC<11>{}); }
                 buf ^= 1;
-            };
-            period(pipe::IC<1>{}, pipe::IC<0>{});
-            for (int m = 1; m < P - 1; ++m) period(pipe::IC<0>{}, pipe::IC<0>{});
-            period(pipe::IC<0>{}, pipe::IC<1>{});
+            }
 
-        // ---- epilogue.  Everything asynchronous (next tile's band, its first weight fragments) lands first: the compiler owns
-        // the schedule and the register allocation from here to the vmcnt(0) at the next tile start.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        // acc[ni][mi][r]: pixel q' = q0 + 256 wm + 32 mi + l31, cout = cw + 32 ni + 8 (r >> 2) + 4 h + (r & 3).  Group pairs (0,1)
-        // and (2,3) are exchanged between the lane halves (v_permlane32_swap): every lane stores 16 bytes = eight consecutive
-        // couts; the four stores of a pixel fragment complete one 128-byte line per pixel.
-        {
-            const int cw = cur.n0 + wn * 64;
+            // ---- epilogue.  Everything asynchronous (next tile's band and first weight steps, the over-run weight loads) lands
+            // first: the compiler owns the schedule and the register allocation from here to the next tile start.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            // acc[ni][mi][r]: pixel q' = q0 + 32 NF wm + 32 mi + l31, cout = cw + 32 ni + 8 (r >> 2) + 4 h + (r & 3).  Group pairs
+            // (0,1) and (2,3) are exchanged between the lane halves (v_permlane32_swap): every lane stores 16 bytes = eight
+            // consecutive couts; the four stores of a pixel fragment complete one 128-byte line per pixel.
+            // split destination (1x1 only: the data gradient of the fusion concat): cout tiles at or past split_c go to y2 / gate2
+            const bool second = a.split_c > 0 && cur.n0 >= a.split_c;
+            const int epi = second ? a.epi2 : a.epi;
+            char* const ybase = second ? a.y2 : a.y;
+            const char* const gbase = second ? a.gate2 : a.gate;
+            const int y_hp = second ? a.y2_hp : a.y_hp, y_wp = second ? a.y2_wp : a.y_wp, y_ld = second ? a.y2_ld : a.y_ld, y_pad = second ? a.y2_pad : a.y_pad;
+            const int g_hp = second ? a.g2_hp : a.g_hp, g_wp = second ? a.g2_wp : a.g_wp, g_ld = second ? a.g2_ld : a.g_ld, g_pad = second ? a.g2_pad : a.g_pad;
+            const int cw = cur.n0 + wn * 64;                            // first cout of this wave (bias / dropout index)
+            const int cy = cw - (second ? a.split_c : 0);               // ... within its destination
             f32x4 bias[2][4];
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     bias[ni][j] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cw + ni * 32 + 8 * j + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int q = cur.q0 + wm * NF * 32 + l31;
-            int n = q / t.hwp;
-            const int rem = q - n * t.hwp;
+            int qq = cur.q0 + wm * NF * 32 + l31;
+            int n = qq / t.hwp;
+            const int rem = qq - n * t.hwp;
             int oy = rem / wp, fx = rem - oy * wp;
             const int H = t.hwp / wp;
-            int qq = q;
+            const int Wo = wp - 2 * t.xpad;
 #pragma unroll
             for (int mi = 0; mi < NF; ++mi) {
-                const bool ok = qq < t.qtot && fx >= 1 && fx <= wp - 2;
-                const int ox = fx - 1;
-                T* ypix = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld + cw + 8 * h;
+                const bool ok = qq < t.qtot && fx >= t.xpad && fx < wp - t.xpad;
+                const int ox = fx - t.xpad;
+                T* ypix = (T*)ybase + (size_t)((n * y_hp + oy + y_pad) * y_wp + (ox + y_pad)) * (size_t)y_ld + cy + 8 * h;
                 u32x4 gt[2][2];
                 if ((epi & DBX_EPI_GATE) && ok) {
-                    const T* gpix = (const T*)a.gate + (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld + cw + 8 * h;
+                    const T* gpix = (const T*)gbase + (size_t)((n * g_hp + oy + g_pad) * g_wp + (ox + g_pad)) * (size_t)g_ld + cy + 8 * h;
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                         for (int jp = 0; jp < 2; ++jp) gt[ni][jp] = *(const u32x4*)(gpix + ni * 32 + 16 * jp);
                 }
+                const unsigned mpix = (unsigned)((n * H + oy) * Wo + ox);   // output pixel index (dropout counter)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
@@ -286,10 +359,10 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
                             }
-                            if ((epi & DBX_EPI_ACCUM) && ok) {
-                                const T* o = ypix - 8 * h + ni * 32 + 8 * j + 4 * h;
+                            if (epi & DBX_EPI_DROPHASH) {               // nn.Dropout(0.5): keep bit of (pixel, cout), kept values x 2
+                                const unsigned kb = dbx_drop_bits4(a.drop_seed, mpix, (unsigned)(cw + ni * 32 + 8 * j + 4 * h) >> 2);
 #pragma unroll
-                                for (int i = 0; i < 4; ++i) v[i] += to_f32(o[i]);
+                                for (int i = 0; i < 4; ++i) v[i] = ((kb >> i) & 1u) ? v[i] * 2.f : 0.f;
                             }
                             T p[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
                             pk[jj] = *(const u32x2*)p;
@@ -298,7 +371,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                         const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                         const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                         u32x4 o = (u32x4){r0[0], r1[0], r0[1], r1[1]};
-                        if (ok) {
+                        if (ok && !(t.dbg & 2)) {
                             if (epi & DBX_EPI_GATE) o = gate_packed16(o, gt[ni][jp]);
                             *(u32x4*)(ypix + ni * 32 + 16 * jp) = o;
                         }
@@ -316,39 +389,39 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                     oy = rr / wp; fx = rr - oy * wp;
                 }
             }
-        }
         };
         if (cur.nf == 8) body(pipe::IC<8>{});
         else body(pipe::IC<7>{});
-        if (nxt_item >= t.items) break;
+        if (!more) break;
         item = nxt_item;
         cur = nxt;
     }
 }
 
 // tile schedule: units of WM fragments; tiles of 7..8 units, their number rounded up to fill whole rounds of CUs
-static inline WsArgs ws_schedule(long long qtot, int hwp, int wm, int ntile_n, int ncu) {
+static inline WsArgs ws_schedule(long long qtot, int hwp, int wm, int ntile_n, int ncu, int xpad) {
     WsArgs t;
     const long long units = (qtot + 32 * wm - 1) / (32 * wm);
     long long mt = (units + 7) / 8;
     const long long wgs = mt * ntile_n;
     if (wgs > ncu) {
         const long long up = (wgs + ncu - 1) / ncu * ncu / ntile_n;     // tiles that fill the last round
-        if (up > mt && units / up >= 6) mt = up;
+        if (up > mt && units / up >= 7) mt = up;                        // (the kernel has 7- and 8-unit tiles)
     }
     t.mt = (int)mt; t.base = (int)(units / mt); t.extra = (int)(units % mt);
-    t.items = (int)(mt * ntile_n); t.hwp = hwp; t.qtot = (int)qtot;
+    t.items = (int)(mt * ntile_n); t.hwp = hwp; t.qtot = (int)qtot; t.xpad = xpad;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DBX_WS_DBG"); dbg = e ? atoi(e) : 0; } t.dbg = dbg; }
     return t;
 }
 
-template <typename T, int WM>
-static int launch_conv_ws(const ConvArgs& a, int n, int h, hipStream_t s) {
+template <typename T, int WM, int KS>
+static int launch_conv_ws(const ConvArgs& a, int n, int h, int xpad, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        constexpr int smem = 2 * ws::pieces(WM) * 1024;
+        constexpr int smem = 2 * ws::pieces(WM, KS) * 1024 + ws::D * (256 / WM) * 32;
         static_assert(smem <= 160 * 1024, "LDS budget");
         static bool attr_set = false;
         if (!attr_set) {
-            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<T, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<T, WM, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
         static int ncu = 0;
@@ -357,9 +430,9 @@ static int launch_conv_ws(const ConvArgs& a, int n, int h, hipStream_t s) {
             DBX_HIP(hipGetDevice(&dev));
             DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         }
-        const WsArgs t = ws_schedule((long long)n * h * a.x_wp, h * a.x_wp, WM, a.ntile_n, ncu);
+        const WsArgs t = ws_schedule((long long)n * h * a.x_wp, h * a.x_wp, WM, a.ntile_n, ncu, xpad);
         const int grid = t.items < ncu ? t.items : ncu;
-        hipLaunchKernelGGL((conv3x3_ws_kernel<T, WM>), dim3(grid), dim3(256), smem, s, a, t);
+        hipLaunchKernelGGL((conv3x3_ws_kernel<T, WM, KS>), dim3(grid), dim3(256), smem, s, a, t);
         DBX_LAUNCH_CHECK();
     }
     return DBX_OK;

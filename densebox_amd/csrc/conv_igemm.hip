@@ -725,11 +725,11 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
     }
 }
 
-#include "conv3x3_pipe.hpp"
-#ifdef DBX_LAB
-#include "conv3x3_pw4.hpp"
-#endif
 #include "conv3x3_ws.hpp"
+#ifdef DBX_LAB                                   // superseded experiments, kept for tools/band_lab.hip
+#include "../../tools/lab_kernels/conv3x3_pipe.hpp"
+#include "../../tools/lab_kernels/conv3x3_pw4.hpp"
+#endif
 
 // ------------------------------------------------------------------------------------------------ v4: 64 -> 64 channels, 3x3
 // conv1_2 (forward and dgrad) at 240x240: N = 64 couts is too narrow for the band kernel -- every 512-pixel tile re-stages
@@ -989,7 +989,9 @@ static int64_t packed_k_elems(const dbx_conv_desc* d) {
 }
 
 extern "C" int64_t dbx_conv_packed_elems(const dbx_conv_desc* d) {
-    return (int64_t)d->cout_pad * packed_k_elems(d);
+    // 3x3 layers that may be packed in fragment order: the ws kernel's weight stream over-runs a tile's image by D steps
+    const int64_t slack = (d->cout_pad % 128 == 0 && d->cin_pad % 64 == 0 && (d->kh == 3 || d->kh == 1)) ? (int64_t)ws::D * 8192 / dbx_esize(d->dtype) : 0;
+    return (int64_t)d->cout_pad * packed_k_elems(d) + slack;
 }
 
 template <typename T, int BM, int BN, int WM, int WN, bool SMALLC>
@@ -1170,27 +1172,40 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     }
     DBX_REQUIRE(a.M > 0 && (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < (int64_t)1 << 40, "conv: empty or oversized input");
 
-    // 3x3 / pad 1 on congruent frames, 16-bit, wide layers with enough tiles to fill the chip: register-streamed weights
-    // (conv3x3_ws.hpp).  It needs the weights in fragment order: a launch takes it iff the caller says so (DBX_CONV_WFRAG),
+    // Wide 16-bit layers with enough tiles to fill the chip: register-streamed weights (conv3x3_ws.hpp) -- the 3x3 / pad 1
+    // backbone layers on congruent frames and the 1x1 head GEMMs (768 -> 512 heads forward; its split-destination data
+    // gradient).  The kernel needs the weights in fragment order: a launch takes it iff the caller says so (DBX_CONV_WFRAG);
     // dbx_conv_plan() reports it whenever the problem qualifies.
     {
         const bool wfrag = d->epilogue & DBX_CONV_WFRAG;
-        bool ws_ok = !smallc && sizeof(T) == 2 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 && ws_enabled() &&
-                     !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK | DBX_EPI_DROPHASH)) && !y2 &&
-                     d->cin_pad % 64 == 0 && d->cin_pad >= 128 && y->c == d->cout_pad && d->cout_pad % 128 == 0 &&
+        const bool k3 = d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1;
+        const bool k1 = d->kh == 1 && d->kw == 1 && d->cpad == 0 && x->pad <= 1 && d->cin_pad % 128 == 0 && d->cout_pad % 256 == 0;
+        const int ctot = y2 ? split_c + y2->c : y->c;                                   // couts over both destinations
+        bool ws_ok = !smallc && sizeof(T) == 2 && (k3 || k1) && ws_enabled() &&
+                     !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK | DBX_EPI_ACCUM)) && (k1 || !(d->epilogue & DBX_EPI_DROPHASH)) &&
+                     (k1 || !y2) && d->cin_pad % 64 == 0 && d->cin_pad >= 128 && ctot == d->cout_pad && d->cout_pad % 128 == 0 &&
                      (x->c_off * ES) % 128 == 0 && (y->c_off * ES) % 16 == 0 && (y->ld * ES) % 16 == 0;
+        {   // the kernel's epilogue kinds: plain / ReLU / ReLU-gate (3x3), plain / hash dropout / plain + gated second destination (1x1)
+            const int kk = d->epilogue & (DBX_EPI_RELU | DBX_EPI_GATE | DBX_EPI_DROPHASH);
+            if (y2) ws_ok = ws_ok && kk == 0 && (epi2 & (DBX_EPI_RELU | DBX_EPI_GATE | DBX_EPI_DROPHASH | DBX_EPI_BIAS)) == DBX_EPI_GATE;
+            else if (k3) ws_ok = ws_ok && (kk == 0 || kk == DBX_EPI_RELU || kk == DBX_EPI_GATE);
+            else ws_ok = ws_ok && (kk == 0 || kk == DBX_EPI_DROPHASH);
+        }
+        if (ws_ok && y2) ws_ok = split_c % 256 == 0 && y2->c % 256 == 0 && !(epi2 & DBX_EPI_ACCUM) && (y2->c_off * ES) % 16 == 0 && (y2->ld * ES) % 16 == 0;
         const int wm = d->cout_pad % 256 == 0 ? 1 : 2;
         const long long qtot = (long long)x->n * x->h * a.x_wp;
         if (ws_ok) {
             ws_ok = (long long)x->h * a.x_wp >= 256 * wm + 8 && qtot < (1ll << 30) &&                   // one image seam per tile
-                    (qtot / (256 * wm)) * (y->c / (256 / wm)) >= 192;                                       // fills the chip
+                    (qtot / (256 * wm)) * (ctot / (256 / wm)) >= 192;                                       // fills the chip
             if ((d->epilogue & DBX_EPI_GATE) && gate) ws_ok = ws_ok && (gate->c_off * ES) % 16 == 0 && (gate->ld * ES) % 16 == 0;
+            if (y2 && (epi2 & DBX_EPI_GATE) && gate2) ws_ok = ws_ok && (gate2->c_off * ES) % 16 == 0 && (gate2->ld * ES) % 16 == 0;
         }
         if (wfrag) DBX_REQUIRE(ws_ok, "conv: DBX_CONV_WFRAG weights, but the problem does not qualify for the ws kernel (ask dbx_conv_plan)");
         if (ws_ok && (wfrag || plan)) {
-            a.ntile_n = y->c / (256 / wm);
-            if (wm == 1) DBX_SELECT(DBX_K_WS, 256, 256, "conv3x3_ws_kernel", (launch_conv_ws<T, 1>(a, x->n, x->h, s)));
-            DBX_SELECT(DBX_K_WS, 512, 128, "conv3x3_ws_kernel", (launch_conv_ws<T, 2>(a, x->n, x->h, s)));
+            a.ntile_n = ctot / (256 / wm);
+            if (k1) DBX_SELECT(DBX_K_WS, 256, 256, "conv1x1_ws_kernel", (launch_conv_ws<T, 1, 1>(a, x->n, x->h, x->pad, s)));
+            if (wm == 1) DBX_SELECT(DBX_K_WS, 256, 256, "conv3x3_ws_kernel", (launch_conv_ws<T, 1, 3>(a, x->n, x->h, 1, s)));
+            DBX_SELECT(DBX_K_WS, 512, 128, "conv3x3_ws_kernel", (launch_conv_ws<T, 2, 3>(a, x->n, x->h, 1, s)));
         }
     }
     // 3x3 / pad 1 on congruent frames (x.pad == 1), 16-bit, plain NHWC epilogue: the band kernel over the linearised frame
@@ -1207,6 +1222,7 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             a.ntile_n = y->c / 256; a.nblocks = tiles256 * a.ntile_n;
 #ifdef DBX_LAB
             if (conv_variant() == 5 && (d->cin_pad * ES) % 128 == 0) return launch_conv_pipe<T, 5>(a, s);
+            if (conv_variant() == 7 && (d->cin_pad * ES) % 128 == 0) return launch_conv_pw4<T, 0>(a, s);
 #endif
             DBX_SELECT(DBX_K_BAND, 256, 256, "conv3x3_band_kernel", (launch_conv_band<T, 256, 256, 2, 2, 4>(a, s)));
         }
@@ -1304,8 +1320,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int co, int ci, 
         const float v = w[i];
         if (mode == 0) wp[(int64_t)(row_off + o) * ktot + (int64_t)t * cin_pad + k_off + c] = from_f32<T>(v);
         else if (mode == 1) wp[(int64_t)(row_off + c) * ktot + (int64_t)(taps - 1 - t) * cin_pad + k_off + o] = from_f32<T>(v);
-        else if (mode == 4) wp[dbx_frag_index(row_off + o, t, k_off + c, cin_pad, rows_pad)] = from_f32<T>(v);
-        else wp[dbx_frag_index(row_off + c, taps - 1 - t, k_off + o, cin_pad, rows_pad)] = from_f32<T>(v);
+        else if (mode == 4) wp[dbx_frag_index(row_off + o, t, k_off + c, cin_pad, rows_pad, taps)] = from_f32<T>(v);
+        else wp[dbx_frag_index(row_off + c, taps - 1 - t, k_off + o, cin_pad, rows_pad, taps)] = from_f32<T>(v);
     }
 }
 
@@ -1318,8 +1334,9 @@ static int pack_weight_t(int mode, const float* w, int co, int ci, int kh, int k
     const bool fwd = mode == 0 || mode == 4;
     const int rows = fwd ? co : ci, cols = fwd ? ci : co;
     DBX_REQUIRE(row_off + rows <= rows_pad && k_off + cols <= cin_pad, "pack_weight: slice out of range");
-    if (mode >= 4) DBX_REQUIRE(sizeof(T) == 2 && kh == 3 && kw == 3 && rows_pad % 128 == 0 && cin_pad % 64 == 0,
-                               "pack_weight: fragment order needs a 16-bit 3x3 layer, rows_pad %% 128 == 0, cin_pad %% 64 == 0");
+    if (mode >= 4) DBX_REQUIRE(sizeof(T) == 2 && ((kh == 3 && kw == 3 && rows_pad % 128 == 0 && cin_pad % 64 == 0) ||
+                                                 (kh == 1 && kw == 1 && rows_pad % 256 == 0 && cin_pad % 128 == 0)),
+                               "pack_weight: fragment order needs a 16-bit 3x3 layer (rows_pad %% 128, cin_pad %% 64) or 1x1 layer (rows_pad %% 256, cin_pad %% 128)");
     const int64_t total = (int64_t)co * ci * kh * kw;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(pack_weight_kernel<T>, dim3(blocks), dim3(256), 0, s, w, co, ci, kh * kw, mode, (T*)wp, ktot,

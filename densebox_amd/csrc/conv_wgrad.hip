@@ -907,7 +907,9 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     const long long steps = (p.Q + 31) / 32;
     // aim for ~4 workgroups per CU (2 resident per CU); the c8 kernel streams dz once: 2 workgroups per CU suffice
     // row3: one 512-thread workgroup per CU, three full rounds of 256 workgroups
-    long long splits = ((p.row3 || p.wide ? 768 : p.c8 ? 512 : 1024) + tiles - 1) / tiles;
+    static int wgs_big = -1;                                   // DBX_WGRAD_WGS: target workgroup count of the row3 / wide kernels (A/B)
+    if (wgs_big < 0) { const char* e = getenv("DBX_WGRAD_WGS"); wgs_big = e ? atoi(e) : 768; }
+    long long splits = ((p.row3 || p.wide ? wgs_big : p.c8 ? 512 : 1024) + tiles - 1) / tiles;
     const long long max_by_steps = steps / 16 > 0 ? steps / 16 : 1;   // at least 16 K-steps (512 rows) per split
     if (splits > max_by_steps) splits = max_by_steps;
     if (splits > (p.c8 ? 512 : 256)) splits = p.c8 ? 512 : 256;

@@ -37,9 +37,12 @@ class GradReducer:
     bucket is a contiguous range of the flat buffer that can be sent while shallower layers are still computing.
     """
 
-    def __init__(self, named_params, order, bucket_bytes=8 << 20, group=None):
+    def __init__(self, named_params, order, bucket_bytes=8 << 20, group=None, always_reduce=False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # always_reduce: run the collectives even in a world of one (exercises the RCCL communicator, its stream and the
+        # wait() ordering on a single-GPU box; SUM over one rank is the identity)
+        self.collective = self.world > 1 or (always_reduce and dist.is_initialized())
         named = dict(named_params)
         self.order = [n for n in order if n in named]
         dev = next(iter(named.values())).device
@@ -76,7 +79,7 @@ class GradReducer:
         """Called by the engine right after the kernels producing these gradients were enqueued."""
         for n in names:
             self._ready_hi = max(self._ready_hi, self.range[n][1])
-        if self.world > 1 and self._ready_hi - self._sent_hi >= self.bucket_elems:
+        if self.collective and self._ready_hi - self._sent_hi >= self.bucket_elems:
             self._send(self._ready_hi)
 
     def _send(self, hi):
@@ -87,7 +90,7 @@ class GradReducer:
             self._sent_hi = hi
 
     def finish(self):
-        if self.world > 1:
+        if self.collective:
             self._send(self.flat.numel())
             for w in self._works:
                 w.wait()          # makes the current stream wait for the collective; does not block the host
@@ -98,18 +101,19 @@ class DataParallel:
     """Wraps a densebox_amd network for data-parallel training.  ``step(...)`` = forward, fused loss with the global
     mining constants, backward with overlapped all-reduce, fused SGD."""
 
-    def __init__(self, net, optimizer, bucket_bytes=8 << 20):
+    def __init__(self, net, optimizer, bucket_bytes=8 << 20, always_reduce=False):
         self.net, self.opt = net, optimizer
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.ctl = None
-        if self.world > 1:
+        self.collective = self.world > 1 or (always_reduce and dist.is_initialized())
+        if self.collective:
             for p in net.parameters():                       # replicate rank 0's weights
                 dist.broadcast(p.data, src=0)
             # tiny host-side control collectives (positive counts) go over gloo: no device sync on the data path
             self.ctl = dist.new_group(backend='gloo') if dist.get_backend() != 'gloo' else dist.group.WORLD
         eng = net.engine()
-        self.reducer = GradReducer(net.named_parameters(), eng.grad_order(), bucket_bytes)
+        self.reducer = GradReducer(net.named_parameters(), eng.grad_order(), bucket_bytes, always_reduce=always_reduce)
         eng.grad_sink = self.reducer
 
     def close(self):
@@ -121,7 +125,7 @@ class DataParallel:
     def global_positive_num(self, bbox, labels=None):
         from . import labels as LB
         p = int(LB.positive_count(bbox, labels).sum())
-        if self.world > 1:
+        if self.collective:
             t = torch.tensor([p], dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl)
             p = int(t.item())

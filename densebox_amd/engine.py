@@ -233,15 +233,33 @@ class Engine:
             self._plans_conv[key] = ent
         return ent
 
-    def _w_heads1(self, dt):
+    def _w_heads1(self, dt, frag=False):
         heads = _HEADS[self.kind]
         ws = [self._param('conv5_1_%s.weight' % s) for s, _ in heads]
+        mode = 4 if frag else 0
 
         def build(out):
             for i, w in enumerate(ws):
-                out = self._pack(dt, 0, w, 512 * len(ws), 768, 1, 1, out=out, row_off=512 * i)
+                out = self._pack(dt, mode, w, 512 * len(ws), 768, 1, 1, out=out, row_off=512 * i)
             return out
-        return self._packed(('heads1', 0, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+        return self._packed(('heads1', mode, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+
+    def _frag_heads(self, P, dt, which):
+        """Fragment-order weights for the heads' 768 -> 512 nh GEMM ('f') / its split-destination data gradient ('b')?"""
+        key = ('heads1', which)
+        r = P.frag.get(key)
+        if r is None:
+            B, nh = P.B, len(_HEADS[self.kind])
+            if which == 'f':
+                r = self.conv_plan(dt, B['fusion'].view(), B['hid'].view(), 1, 1, 0, 768, 512 * nh, _lib.EPI_BIAS | _lib.EPI_DROPHASH)[2]
+            elif 'd_hid' in B and dt != _lib.F32:
+                dv = B['d_ups'].view()
+                both = View(dv.ptr, dv.n, dv.h, dv.w, dv.pad, 768, 0, 768)      # both destinations' couts, for planning only
+                r = self.conv_plan(dt, B['d_hid'].view(), both, 1, 1, 0, 512 * nh, 768, 0)[2]
+            else:
+                r = False
+            P.frag[key] = r
+        return r
 
     def _weight_getters(self, dt, train, P):
         """Touch every packed weight / bias the step uses (same calls as forward_raw / backward_raw make)."""
@@ -251,7 +269,7 @@ class Engine:
         for stem, cin, cout in _BACKBONE:
             self._w_fwd(dt, stem, P.cin0 if cin == 3 else cin, max(64, cout), frag=self._frag(P, dt, stem, 'f'))
             self._bias([stem], max(64, cout))
-        self._w_heads1(dt)
+        self._w_heads1(dt, frag=train and self._frag_heads(P, dt, 'f'))
         self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
         for s_, _ in heads:
             self._w_fwd(dt, 'conv5_2_' + s_, 512, 64)
@@ -263,7 +281,7 @@ class Engine:
         if train:
             for stem, cin, cout in _BACKBONE[1:]:
                 self._w_bwd(dt, stem, max(64, cin), cout, frag=self._frag(P, dt, stem, 'b'))
-            self._w_heads1_bwd(dt)
+            self._w_heads1_bwd(dt, frag=self._frag_heads(P, dt, 'b'))
             if kind != 'DenseBox':
                 self._w_bwd(dt, 'conv6_3_det', 64, P.crf)
                 self._w_bwd(dt, 'conv6_2_det', 64, 64)
@@ -273,6 +291,8 @@ class Engine:
         """Re-pack all parameters with ONE kernel launch when any of them changed (e.g. after an optimizer step)."""
         params = [p for _, p in self.net.named_parameters()]
         lay = tuple(self._frag(P, dt, st, wh) for st, _, _ in _BACKBONE for wh in ('f', 'b'))   # layouts the kernels of this plan want
+        if train:
+            lay += (self._frag_heads(P, dt, 'f'), self._frag_heads(P, dt, 'b'))
         sig = (dt, train, tuple((p._version, p.data_ptr()) for p in params), lay)
         if sig == self._wsig:
             return
@@ -341,7 +361,7 @@ class Engine:
                 cin_pad = P.cin0 if cin == 3 else cin
                 r = self.conv_plan(dt, vw(src), vw(dst), 3, 3, 1, cin_pad, max(64, cout), _lib.EPI_BIAS | _lib.EPI_RELU)[2]
             else:
-                dz, dx = _BWD_IO[stem]
+                dz, dx = _BWD_IO.get(stem, (None, None))           # conv1_1 has no data gradient
                 r = self.conv_plan(dt, vw(dz), vw(dx), 3, 3, 1, cout, max(64, cin), _lib.EPI_GATE)[2] if dz in B else False
             P.frag[key] = r
         return r
@@ -489,8 +509,10 @@ class Engine:
             elif P.drop_active:
                 dm = self._fill_dropout(P, heads)       # injected masks (parity tests)
                 epi |= _lib.EPI_DROPMASK
-            self._conv(dt, B['fusion'].view(), B['hid'].view(), self._w_heads1(dt),
-                       self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh), 1, 1, 0, 768, 512 * nh, epi,
+            hfrag = (epi & _lib.EPI_DROPMASK) == 0 and self._frag_heads(P, dt, 'f')
+            self._conv(dt, B['fusion'].view(), B['hid'].view(), self._w_heads1(dt, frag=hfrag),
+                       self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh), 1, 1, 0, 768, 512 * nh,
+                       epi | (_lib.CONV_WFRAG if hfrag else 0),
                        dropmask=dm, dm_ld=512 * nh, drop_seed=P.drop_seed if P.drop_hash else 0)
             for i, (stem, k) in enumerate(heads):
                 o = torch.empty((n, k, h4, w4), dtype=torch.float32, device=dev)
@@ -553,15 +575,16 @@ class Engine:
                             lambda old: self._pack(dt, mode, w, rows_pad, cin_pad, w.shape[2], w.shape[3], out=old),
                             (w._version, w.data_ptr()))
 
-    def _w_heads1_bwd(self, dt):
+    def _w_heads1_bwd(self, dt, frag=False):
         heads = _HEADS[self.kind]
         ws = [self._param('conv5_1_%s.weight' % s) for s, _ in heads]
+        mode = 5 if frag else 1
 
         def build(out):
             for i, w in enumerate(ws):
-                out = self._pack(dt, 1, w, 768, 512 * len(ws), 1, 1, out=out, k_off=512 * i)
+                out = self._pack(dt, mode, w, 768, 512 * len(ws), 1, 1, out=out, k_off=512 * i)
             return out
-        return self._packed(('heads1', 1, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+        return self._packed(('heads1', mode, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
 
     def _wgrad(self, dt, dz, x, kh, kw, cpad, co, ci, dw, db, accumulate=0):
         need = self.L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dz), C.byref(x), kh, kw)
@@ -717,12 +740,13 @@ class Engine:
         for i, (stem, _) in enumerate(heads):
             G['conv5_1_%s.weight' % stem] = dw1[512 * i:512 * (i + 1)]
             G['conv5_1_%s.bias' % stem] = db1[512 * i:512 * (i + 1)]
-        w1t = self._w_heads1_bwd(dt)                          # [768 rows][512*nh]
+        bfrag = dt != _lib.F32 and self._frag_heads(P, dt, 'b')
+        w1t = self._w_heads1_bwd(dt, frag=bfrag)              # [768 rows][512*nh] (or its fragment-order image)
         row_bytes = 512 * nh * _lib.ESIZE[dt]
         c34 = B['fusion'].view(512, 256)
         if dt != _lib.F32:
             # one pass over d_hid for both branches of the concat: couts 0..511 -> d_ups, 512..767 -> d_c34 (ReLU-gated)
-            d = ConvDesc(dt, 1, 1, 0, 512 * nh, 768, 0, 0)
+            d = ConvDesc(dt, 1, 1, 0, 512 * nh, 768, _lib.CONV_WFRAG if bfrag else 0, 0)
             prof = self.profile
             if prof is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -732,7 +756,10 @@ class Engine:
             if prof is not None:
                 ev1.record()
                 hv = B['d_hid'].view()
-                prof.append({'kernel': 'conv_igemm_dma_kernel<%s,256,256>' % ('f16', 'bf16', 'f32')[dt],
+                dv = B['d_ups'].view()
+                both = View(dv.ptr, dv.n, dv.h, dv.w, dv.pad, 768, 0, 768)
+                prof.append({'kernel': self.conv_plan(dt, hv, both, 1, 1, 0, 512 * nh, 768, 0)[1] if bfrag else
+                             'conv_igemm_dma_kernel<%s,256,256>' % ('f16', 'bf16', 'f32')[dt],
                              'flops': 2.0 * hv.n * hv.h * hv.w * 512 * nh * 768, 'start': ev0, 'end': ev1})
         else:
             self._conv(dt, B['d_hid'].view(), B['d_ups'].view(), w1t, None, 1, 1, 0, 512 * nh, 512, 0)

@@ -228,6 +228,41 @@ def gen_nets():
     print('net_DenseBox_1080p.npz', d['score_sub'].shape, d['keep'])
 
 
+# ----------------------------------------------------------------------------- B2. checkpoints (state_dict interop)
+CKPT_SEED = 23
+
+
+def gen_checkpoints():
+    """What the reference writes with torch.save(net.state_dict()) (DenseBox.py:2206) and reads back with load_state_dict
+    (:1989-1994): per net the key order, every entry's shape / dtype / float64 sum / L1 norm, the groups of keys that share
+    storage (the aliased conv wrappers), the small tensors in full, and the eval forward of a net carrying these weights."""
+    x = synth.synth_images(1, 240, 240, seed=6)
+    d = {'ckpt_seed': CKPT_SEED}
+    for kind in NETS:
+        net = getattr(R, kind)(synth.vgg19_standin(seed=0))
+        synth.fill_params_(net, CKPT_SEED)
+        sd = net.state_dict()
+        keys = list(sd.keys())
+        d[kind + '_keys'] = np.array(keys)
+        d[kind + '_shapes'] = np.array([','.join(str(v) for v in sd[k].shape) for k in keys])
+        d[kind + '_dtypes'] = np.array([str(sd[k].dtype) for k in keys])
+        d[kind + '_sums'] = np.array([float(sd[k].double().sum()) for k in keys])
+        d[kind + '_l1'] = np.array([float(sd[k].double().abs().sum()) for k in keys])
+        ptr = {}
+        for i, k in enumerate(keys):
+            ptr.setdefault(sd[k].data_ptr(), []).append(i)
+        d[kind + '_alias'] = np.array([';'.join(str(i) for i in g) for g in ptr.values() if len(g) > 1])
+        for k in keys:
+            if sd[k].numel() <= 4096:
+                d['%s_val_%s' % (kind, k)] = t2n(sd[k])
+        net.eval()
+        with torch.no_grad():
+            for i, o in enumerate(net.forward(x)):
+                d['%s_out_%d' % (kind, i)] = t2n(o)
+    np.savez_compressed(os.path.join(OUT, 'checkpoints.npz'), **d)
+    print('checkpoints.npz', {k: len(d[k + '_keys']) for k in NETS}, 'alias groups', {k: len(d[k + '_alias']) for k in NETS})
+
+
 # ----------------------------------------------------------------------------- C. captured training steps
 class _SynthSet(torch.utils.data.Dataset):
     """Replaces the JPEG-reading Dataset classes: same tuple layout as
@@ -535,8 +570,9 @@ def gen_datasets():
 
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ['labels', 'decode', 'nets', 'train', 'datasets']
+    which = sys.argv[1:] or ['labels', 'decode', 'nets', 'checkpoints', 'train', 'datasets']
     for w in which:
-        {'labels': gen_labels, 'decode': gen_decode, 'nets': gen_nets, 'train': gen_train, 'datasets': gen_datasets}[w]()
+        {'labels': gen_labels, 'decode': gen_decode, 'nets': gen_nets, 'checkpoints': gen_checkpoints, 'train': gen_train,
+         'datasets': gen_datasets}[w]()
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print('total fixture bytes', sz)

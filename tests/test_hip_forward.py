@@ -2,8 +2,10 @@
 
 Tolerances (outputs are O(1); loc-type outputs O(10)):
   f32  : |err| <= 1e-4 * max(1, |ref|)   exact-fp32 MFMA, only summation order differs
-  f16  : |err| <= 1e-3 * scale + fp16 activation rounding accumulated over 13 layers -> checked as 4e-3 * max|ref|
-  bf16 : 8x coarser mantissa -> 3e-2 * max|ref|
+  f16  : fp16 activation rounding accumulated over 13 layers.  Achieved (profiles/r02_lowprec_errors.json, tools/gpu_lowprec_err.py):
+         bbox / landmark-offset maps 0.6-1.0e-3, score / heat maps 1.3-1.7e-3, the refine score (two more convs) 2.8e-3 of
+         max|ref|; rms 2-9e-4.  Checked as achieved + 20 %: 3.4e-3 * max|ref|
+  bf16 : 8x coarser mantissa: achieved 0.6-1.2e-2, refine score 2.7e-2 -> 3e-2 * max|ref|
 """
 import numpy as np
 import pytest
@@ -16,7 +18,7 @@ import densebox_amd as D
 pytestmark = pytest.mark.gpu
 
 KINDS = ['DenseBox', 'DenseBoxLM', 'DenseBoxLMLOC']
-TOL = {'f32': 1e-4, 'f16': 4e-3, 'bf16': 3e-2}
+TOL = {'f32': 1e-4, 'f16': 3.4e-3, 'bf16': 3e-2}
 
 
 def _net(kind, dtype, seed=11):

@@ -39,6 +39,8 @@ CONV_CASES = [  # n, h, w, cin, cout, k, pad
     (2, 20, 28, 64, 64, 3, 1), (3, 17, 23, 128, 256, 3, 1), (1, 30, 30, 512, 512, 3, 1), (2, 15, 15, 768, 1024, 1, 0),
     (2, 14, 14, 64, 64, 5, 0), (1, 33, 9, 256, 128, 3, 1),
     (10, 53, 100, 64, 64, 3, 1),      # ragged 8x32 tiles of the weights-stationary 64->64 kernel
+    (10, 240, 240, 64, 128, 3, 1),    # >= 1024 tiles of 512 pixels: conv3x3_band_kernel<512,128> (conv2_1 at batch 64)
+    (10, 240, 240, 128, 64, 3, 1),    # ... and <512,64> (conv2_1's data gradient)
 ]
 
 
@@ -46,8 +48,10 @@ CONV_CASES = [  # n, h, w, cin, cout, k, pad
 @pytest.mark.parametrize('dtn', ['bf16', 'f16'])
 @pytest.mark.parametrize('case', CONV_CASES)
 def test_conv_forward_kernel(case, dtn, variant, monkeypatch):
-    if variant == 'v1':
-        pytest.skip('v1/v2 selection is per process (env DBX_CONV_VARIANT); v1 is covered by the f32 + small-Cin paths')
+    if variant == 'v1' and os.environ.get('DBX_CONV_VARIANT') != '1':
+        pytest.skip('kernel selection is per process (env DBX_CONV_VARIANT): run by test_forced_kernel_variants_in_subprocesses')
+    if variant == 'dma' and os.environ.get('DBX_CONV_VARIANT') == '1':
+        pytest.skip('this process forces the register-staged v1 kernel')
     n, h, w, ci, co, k, pad = case
     L = _lib.lib()
     dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
@@ -229,7 +233,7 @@ def test_conv_ws_forward(case, dtn):
 
 
 @pytest.mark.parametrize('dtn', ['bf16', 'f16'])
-@pytest.mark.parametrize('case', [(40, 30, 30, 256, 512), (20, 60, 60, 128, 256)])
+@pytest.mark.parametrize('case', [(56, 30, 30, 256, 512), (30, 60, 60, 128, 256)])
 def test_conv_ws_dgrad_gate_and_sliced_views(case, dtn):
     """Data gradient through the ws kernel (pack mode 5, ReLU gate), written into a channel slice of a wider frame and read
     from a channel slice (the fusion concat's conv3_4 slot): dx = conv_transpose(dz, w) * (gate > 0)."""
@@ -263,19 +267,104 @@ def test_pack_fragment_order_matches_documented_index():
     """dbx_pack_weight modes 4/5 against the index formula of include/densebox_hip.h, built with numpy."""
     L = _lib.lib()
     dt = _lib.DTYPE_ID['f16']
-    for co, ci, mode in [(256, 128, 4), (128, 192, 4), (256, 128, 5), (128, 256, 5)]:
+    for co, ci, mode, ks in [(256, 128, 4, 3), (128, 192, 4, 3), (256, 128, 5, 3), (128, 256, 5, 3), (512, 256, 4, 1), (256, 512, 5, 1)]:
         g = torch.Generator(device='cpu').manual_seed(co + ci + mode)
-        wt = torch.randn(co, ci, 3, 3, generator=g)
+        taps = ks * ks
+        wt = torch.randn(co, ci, ks, ks, generator=g)
         rows, k = (co, ci) if mode == 4 else (ci, co)
         got = pack(L, dt, wt.cuda(), k, rows, mode=mode).view(torch.float16).cpu().numpy()
-        w16 = wt.to(torch.float16).numpy().reshape(co, ci, 9)
+        w16 = wt.to(torch.float16).numpy().reshape(co, ci, taps)
         bn = 256 if rows % 256 == 0 else 128
-        kc = k // 64
-        exp = np.zeros(rows * 9 * k, dtype=np.float16)
-        r_, t_, k_ = np.meshgrid(np.arange(rows), np.arange(9), np.arange(k), indexing='ij')
-        ky, kx = t_ // 3, t_ % 3
-        blk = ((((r_ // bn) * (3 * kc) + ky * kc + k_ // 64) * 12 + kx * 4 + (k_ % 64) // 16) * (bn // 32) + (r_ % bn) // 32)
+        exp = np.zeros(rows * taps * k, dtype=np.float16)
+        r_, t_, k_ = np.meshgrid(np.arange(rows), np.arange(taps), np.arange(k), indexing='ij')
+        if ks == 3:
+            kc = k // 64
+            ky, kx = t_ // 3, t_ % 3
+            blk = ((((r_ // bn) * (3 * kc) + ky * kc + k_ // 64) * 12 + kx * 4 + (k_ % 64) // 16) * (bn // 32) + (r_ % bn) // 32)
+        else:
+            blk = ((((r_ // bn) * (k // 128) + k_ // 128) * 8 + (k_ % 128) // 16) * (bn // 32) + (r_ % bn) // 32)
         idx = (blk * 64 + 32 * ((k_ % 16) // 8) + r_ % 32) * 8 + k_ % 8
-        src = w16[r_, k_, t_] if mode == 4 else w16[k_, r_, 8 - t_]
+        src = w16[r_, k_, t_] if mode == 4 else w16[k_, r_, taps - 1 - t_]
         exp[idx.ravel()] = src.ravel()
-        assert np.array_equal(got[:exp.size], exp), (co, ci, mode)
+        assert np.array_equal(got[:exp.size], exp), (co, ci, mode, ks)
+
+
+# ---------------------------------------------------------------- 1x1 GEMMs on the ws kernel (the heads' 768 -> 512 nh conv and its data gradient)
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+def test_conv_ws_1x1_forward_bias_and_hash_dropout(dtn):
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    n, h, w, ci, co = 16, 60, 57, 768, 1024
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(co, ci, 1, 1, generator=g) * (1.0 / ci) ** 0.5).cuda()
+    b = torch.randn(co, generator=g).cuda()
+    ref = F.conv2d(x.to(tdt).float(), wt.to(tdt).float(), b)
+    fx, tx, xv = framed(x, 1, tdt)                                   # framed input (the fusion tensor has a 1-pixel frame)
+    tol = (2e-2 if dtn == 'bf16' else 3e-3)
+    outs = {}
+    for frag in (True, False):
+        for epi in (_lib.EPI_BIAS, _lib.EPI_BIAS | _lib.EPI_DROPHASH):
+            fy, ty, yv = framed(torch.zeros(n, co, h, w), 0, tdt)    # un-framed output (the hidden map)
+            d = ConvDesc(dt, 1, 1, 0, ci, co, epi, 0x1234)
+            plan = _lib.ConvPlan()
+            check(L.dbx_conv_plan(C.byref(d), C.byref(xv), C.byref(yv), C.byref(plan)))
+            assert plan.kernel == _lib.K_WS and plan.name.decode().startswith('conv1x1_ws_kernel<')
+            if frag:
+                d = ConvDesc(dt, 1, 1, 0, ci, co, epi | _lib.CONV_WFRAG, 0x1234)
+            check(L.dbx_conv_forward(C.byref(d), C.byref(xv), ptr(pack(L, dt, wt, ci, co, mode=4 if frag else 0)), ptr(b), C.byref(yv),
+                                     None, None, 0, stream_ptr()))
+            outs[(frag, epi)] = ty.permute(0, 3, 1, 2).float()
+    plain = outs[(True, _lib.EPI_BIAS)]
+    assert torch.allclose(plain, ref, rtol=tol, atol=tol), (plain - ref).abs().max().item()
+    # hash dropout: the same keep bits as the LDS-ring kernel (same seed, pixel and channel counters), kept values doubled
+    a, bb = outs[(True, _lib.EPI_BIAS | _lib.EPI_DROPHASH)], outs[(False, _lib.EPI_BIAS | _lib.EPI_DROPHASH)]
+    assert torch.allclose(a, bb, rtol=tol, atol=tol)
+    big = ref.abs() > 0.1
+    assert torch.equal((a != 0)[big], (bb != 0)[big])
+    keep = (a != 0)[big].float().mean().item()
+    assert 0.45 < keep < 0.55, keep
+    assert torch.allclose(a[big & (a != 0)], 2 * ref[big & (a != 0)], rtol=2 * tol, atol=2 * tol)
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+def test_conv_ws_1x1_split_destination(dtn):
+    """The fusion concat's data gradient on the ws kernel == the LDS-ring kernel's dbx_conv_forward_split (row-major weights)."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    n, h, w, ci, c1, c2 = 16, 60, 60, 1024, 512, 256
+    g = torch.Generator(device='cpu').manual_seed(11)
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    wt = (torch.randn(c1 + c2, ci, 1, 1, generator=g) * (1.0 / ci) ** 0.5).cuda()
+    gate_src = torch.randn(n, c2, h, w, generator=g).cuda()
+    fx, tx, xv = framed(x, 1, tdt)
+    fg, tg, gv = framed(gate_src, 1, tdt)
+    res = []
+    for frag in (False, True):
+        fa, ta, av = framed(torch.zeros(n, c1, h, w), 0, tdt)
+        fb, tb, bv = framed(torch.zeros(n, c2, h, w), 1, tdt)
+        d = ConvDesc(dt, 1, 1, 0, ci, c1 + c2, _lib.CONV_WFRAG if frag else 0)
+        check(L.dbx_conv_forward_split(C.byref(d), C.byref(xv), ptr(pack(L, dt, wt, ci, c1 + c2, mode=4 if frag else 0)), None, C.byref(av),
+                                       None, C.byref(bv), C.byref(gv), c1, _lib.EPI_GATE, stream_ptr()))
+        res.append((ta.float(), tb.float()))
+    tol = (2e-2 if dtn == 'bf16' else 3e-3)
+    ref = F.conv2d(x.to(tdt).float(), wt.to(tdt).float())
+    assert torch.allclose(res[1][0].permute(0, 3, 1, 2), ref[:, :c1], rtol=tol, atol=tol)
+    assert torch.allclose(res[1][1][:, 1:-1, 1:-1].permute(0, 3, 1, 2), ref[:, c1:] * (gate_src.to(tdt).float() > 0), rtol=tol, atol=tol)
+    assert torch.allclose(res[0][0], res[1][0], rtol=tol, atol=tol) and torch.allclose(res[0][1], res[1][1], rtol=tol, atol=tol)
+    assert float(res[1][1][:, 0].abs().sum()) == 0 and float(res[1][1][:, :, -1].abs().sum()) == 0     # frame of y2 untouched
+
+
+def test_forced_kernel_variants_in_subprocesses():
+    """The library picks kernels per process (environment read once): re-run the kernel tests with (a) the register-staged v1
+    conv kernel forced everywhere (the 14 `v1` cases skipped above) and (b) the register-streamed-weights kernel disabled, so
+    that the LDS band kernels it replaced on the wide layers (256x256 / 256x128 tiles) keep their direct oracle comparison."""
+    import subprocess
+    import sys
+    here = os.path.abspath(__file__)
+    for env, sel in (({'DBX_CONV_VARIANT': '1'}, 'test_conv_forward_kernel and v1'),
+                     ({'DBX_WS': '0'}, 'test_conv_forward_kernel and dma')):
+        r = subprocess.run([sys.executable, '-m', 'pytest', here, '-x', '-q', '-m', 'gpu', '-k', sel], capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=1800)
+        assert r.returncode == 0, (env, r.stdout[-3000:])
+        assert ' passed' in r.stdout and 'skipped' not in r.stdout.splitlines()[-1], (env, r.stdout[-500:])

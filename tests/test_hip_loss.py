@@ -102,7 +102,8 @@ def test_fused_loss_vs_reference_capture(golden, name):
     if kind != 'DenseBox':
         for j in range(4):
             assert np.array_equal(dbg['lm_neg_idx'][j].cpu().numpy(), g['s0_neg_idx_%d' % (1 + j)])
-        assert np.array_equal(dbg['mask_lm'][:, 3:4].cpu().numpy(), unpack(g['s0_mask_gray_zone_lm_3'], (n, 1, 60, 60)))
+        for j in range(4):                      # every landmark channel's mask after mining + its gray zone (channel views)
+            assert np.array_equal(dbg['mask_lm'][:, j:j + 1].cpu().numpy(), unpack(g['s0_mask_gray_zone_lm_%d' % j], (n, 1, 60, 60))), j
     assert np.isclose(float(loss.detach()), float(g['s0_loss']), rtol=2e-6)
     loss.backward()
     # dL/d(out) of the loss alone: the oracle's autograd on the same leaf tensors.  (The captured s0_dout of the score /

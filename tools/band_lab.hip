@@ -72,7 +72,7 @@ __global__ void retile_w(const __bf16* wp, __bf16* wt, int co, int ci, int bn) {
     const size_t tot = (size_t)co * 9 * ci;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i % ci; const int tap = (i / ci) % 9; const int o = i / ((size_t)9 * ci);
-        wt[dbx_frag_index(o, tap, c, ci, bn == 256 ? 256 : 128)] = wp[i];
+        wt[dbx_frag_index(o, tap, c, ci, bn == 256 ? 256 : 128, 9)] = wp[i];
     }
 }
 

@@ -1,5 +1,6 @@
-// v5: 3x3 / pad-1 convolution as ONE continuous tap pipeline (forward and dgrad of the wide backbone layers, 16-bit types).
-// Included by conv_igemm.hip (needs ConvArgs, dma_swz, gate_packed16).
+// LAB ONLY (tools/band_lab.hip, -DDBX_LAB) -- measured and superseded by conv3x3_ws.hpp: v5, 3x3 / pad-1 convolution as ONE
+// continuous tap pipeline, 8 waves, A band + W tiles through the LDS (440 k clocks on conv4_2 at batch 64 vs 472 k for the
+// band kernel and 390 k for the ws kernel).  Included by conv_igemm.hip behind DBX_LAB (needs ConvArgs, dma_swz, Mma32).
 //
 // Tile: 256 consecutive pixels of the linearised frame x 256 couts, 8 waves as 2 (pixel halves) x 4 (cout quarters), each wave
 // 128 px x 64 couts on v_mfma_f32_32x32x16 (weights = A operand / accumulator rows, pixels = B operand / accumulator
@@ -15,20 +16,6 @@
 // the barrier of step t publishes the data of step t+1 (every wave waited its own counted vmcnt first) and frees the slot
 // of step t-1 (whose last reads were issued a full step earlier), which is refilled right behind it.
 #pragma once
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <typename T> struct Mma32;
-template <> struct Mma32<_Float16> {
-    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mma32<__bf16> {
-    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
 
 namespace pipe {
 constexpr int BM = 256, BN = 256;
@@ -47,7 +34,6 @@ constexpr int allowed(int t, bool last, int NW) {
     }
     return n;
 }
-template <int N> struct IC { static constexpr int value = N; };
 }  // namespace pipe
 
 // ABL (lab only): timing ablations, results are wrong -- 1: no LDS-DMA in the loop, 2: no fragment reads in the loop, 4: no waits/barriers

@@ -1,3 +1,5 @@
+// LAB ONLY (tools/band_lab.hip, -DDBX_LAB) -- measured and superseded by conv3x3_ws.hpp (each weight fragment is fetched by
+// two waves here: 37 KB of vector-memory traffic per 1024 MFMA-cycles against 22 KB, 482 k clocks against 390 k).
 // v6: 3x3 / pad-1 convolution, four fat waves (one per SIMD, the whole 512-register file each), weights streamed straight
 // into the MFMA operand registers.  Included by conv_igemm.hip (needs ConvArgs, gate_packed16, Mma32 from conv3x3_pipe.hpp).
 //

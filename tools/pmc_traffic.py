@@ -22,4 +22,7 @@ for k in sorted(f, key=lambda k: -(2 * f[k][0] + w.get(k, (0, 1))[0])):
     out[k] = {'launches': n, 'fetch_bytes_per_launch': fetch, 'write_bytes_per_launch': write, 'hbm_bytes_per_launch': fetch + write}
     print('%-100s %8d %14.1f %14.1f %14.1f' % (k[:100], n, fetch / 1e6, write / 1e6, (fetch + write) / 1e6))
 if len(sys.argv) > 3:
-    json.dump(out, open(sys.argv[3], 'w'), indent=1)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_hash
+    json.dump({'csrc_hash': csrc_hash(), 'kernels': out}, open(sys.argv[3], 'w'), indent=1)
