@@ -131,12 +131,60 @@ class DataParallel:
             p = int(t.item())
         return p
 
+    def _stage(self, dev, items):
+        """Host-side loss inputs (boxes, vertices, labels, mining draws; ~10 KB) -> device through ONE pinned buffer and one
+        asynchronous copy, enqueued BEFORE the forward.  A pageable ``.to(device)`` inside the loss would block the host until
+        the whole forward has drained (stream order), and the backward would then start with an empty launch queue."""
+        import numpy as np
+        host = []
+        for t, dt in items:
+            if t is None or (torch.is_tensor(t) and t.is_cuda):
+                host.append(None)
+            else:
+                host.append(torch.as_tensor(np.ascontiguousarray(t) if isinstance(t, np.ndarray) else t).to(dt).contiguous())
+        nbytes = sum((h.numel() * h.element_size() + 15) // 16 * 16 for h in host if h is not None)
+        if nbytes == 0:
+            return [t for t, _ in items]
+        st = self.__dict__.get('_stage_buf')
+        if st is None or st[0].numel() < nbytes:
+            st = (torch.empty(2 * nbytes, dtype=torch.uint8).pin_memory(), torch.empty(2 * nbytes, dtype=torch.uint8, device=dev),
+                  torch.cuda.Event())
+            self._stage_buf = st
+        pin, dbuf, ev = st
+        ev.synchronize()                                   # the previous step's copy has left the pinned buffer
+        out, off = [], 0
+        for (t, dt), h in zip(items, host):
+            if h is None:
+                out.append(t); continue
+            nb = h.numel() * h.element_size()
+            pin[off:off + nb].view(dt).view(h.shape).copy_(h)
+            out.append(dbuf[off:off + nb].view(dt).view(h.shape))
+            off += (nb + 15) // 16 * 16
+        dbuf[:off].copy_(pin[:off], non_blocking=True)
+        ev.record()
+        return out
+
     def step(self, x, bbox, vertices=None, labels=None, rand_neg_indices=None, lm_rand_neg_indices=None,
              positive_num_global=None, **loss_kw):
         net = self.net
         n_global = x.size(0) * self.world
         if positive_num_global is None:
             positive_num_global = self.global_positive_num(bbox, labels if net.KIND == 'DenseBoxLMLOC' else None)
+        if x.is_cuda:
+            import numpy as np
+            from . import labels as LB
+            n = x.size(0)
+            rs = loss_kw.get('rng') or np.random
+            _, half = LB.neg_counts(int(positive_num_global), n_global)
+            if rand_neg_indices is None:                   # same draws, same order as densebox_loss would make
+                rand_neg_indices = np.stack([rs.choice(3600, half, replace=False) for _ in range(n)]) if half else \
+                    np.zeros((n, 0), np.int64)
+            if net.KIND != 'DenseBox' and lm_rand_neg_indices is None:
+                lm_rand_neg_indices = np.stack([np.stack([rs.choice(3600, 1, replace=False) for _ in range(n)])
+                                                for _ in range(4)])
+            bbox, vertices, labels, rand_neg_indices, lm_rand_neg_indices = self._stage(
+                x.device, [(bbox, torch.float32), (vertices, torch.float32), (labels, torch.float32),
+                           (rand_neg_indices, torch.int64), (lm_rand_neg_indices, torch.int64)])
         self.opt.zero_grad(set_to_none=True)
         self.reducer.begin()
         net.engine().sample_offset = self.rank * x.size(0)     # ranks draw different dropout masks (engine._next_drop_seed)
