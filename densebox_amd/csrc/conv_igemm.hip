@@ -1087,11 +1087,12 @@ static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s
     return DBX_OK;
 }
 
-static bool ws_enabled() {           // DBX_WS=0 keeps the LDS band kernels on every layer (A/B testing)
+static int ws_level() {              // DBX_WS=0 keeps the LDS band kernels on every layer, 2 plans ws wherever it can run (A/B testing)
     static int v = -1;
     if (v < 0) { const char* e = getenv("DBX_WS"); v = e ? atoi(e) : 1; }
-    return v != 0;
+    return v;
 }
+static bool ws_enabled() { return ws_level() != 0; }
 static int g_conv_variant_override = -1;   // set by in-tree lab programs that include this file (tools/band_lab.hip)
 static int conv_variant() {          // DBX_CONV_VARIANT=1 forces the register-staged v1 kernel everywhere (A/B testing)
     static int v = -1;
@@ -1201,7 +1202,13 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             if (y2 && (epi2 & DBX_EPI_GATE) && gate2) ws_ok = ws_ok && (gate2->c_off * ES) % 16 == 0 && (gate2->ld * ES) % 16 == 0;
         }
         if (wfrag) DBX_REQUIRE(ws_ok, "conv: DBX_CONV_WFRAG weights, but the problem does not qualify for the ws kernel (ask dbx_conv_plan)");
-        if (ws_ok && (wfrag || plan)) {
+        // Which eligible problems the plan PREFERS on it (same-box A/B inside the training step, profiles/r02_ws_vs_band.txt): the
+        // kernel's fixed cost per tile (prologue, one-wave-per-SIMD epilogue with nothing to overlap it) is amortised over the
+        // K loop, so it wins with >= 512 input channels, with 256 unless the epilogue gates or the layer has 512 couts, and on
+        // the 1x1 heads; the LDS band kernels keep the short-K layers.  A caller may still force it with DBX_CONV_WFRAG.
+        const bool ws_pref = k1 || d->cin_pad >= 512 ||
+                             (d->cin_pad >= 256 && (wm == 2 || (!(d->epilogue & DBX_EPI_GATE) && d->cout_pad < 512)));
+        if (ws_ok && (wfrag || (plan && (ws_pref || ws_level() >= 2)))) {
             a.ntile_n = ctot / (256 / wm);
             if (k1) DBX_SELECT(DBX_K_WS, 256, 256, "conv1x1_ws_kernel", (launch_conv_ws<T, 1, 1>(a, x->n, x->h, x->pad, s)));
             if (wm == 1) DBX_SELECT(DBX_K_WS, 256, 256, "conv3x3_ws_kernel", (launch_conv_ws<T, 1, 3>(a, x->n, x->h, 1, s)));
