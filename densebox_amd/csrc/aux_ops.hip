@@ -480,9 +480,15 @@ extern "C" int dbx_head2_dgrad(int32_t dtype, const dbx_view* d_out, const float
 // laid out as in head2_dgrad (one 16-byte chunk of one head's 512 channels per lane, whole pixels per workgroup);
 // every lane keeps its 8 x V accumulator block in registers, workgroups own fixed image rows, and the per-workgroup
 // partials are summed in a fixed order by head2_wgrad_reduce_kernel (bitwise repeatable).
-template <typename T>
+//
+// DG = true (dbx_head2_backward) also produces the data gradient of head2_dgrad_kernel for the pixel it is accumulating:
+// d_out and the weights are in registers already, so the 1 GB d_hid write overlaps the 1 GB hid read in ONE pass over the
+// pixels instead of a write-only pass followed by a read-only pass (HBM moves ~5 TB/s mixed, ~3.5 TB/s either way alone).
+template <typename T, bool DG>
 __global__ __launch_bounds__(512) void head2_wgrad_kernel(FrameGeo dout, FrameGeo hid, int nh, int slot, float* __restrict__ partial,
-                                                          float* __restrict__ bpartial) {
+                                                          float* __restrict__ bpartial, Head2Args ha, FrameGeo dhid,
+                                                          const unsigned char* __restrict__ mask, int mask_ld, int use_hash,
+                                                          unsigned drop_seed) {
     constexpr int V = Vec<T>::N;
     constexpr int LPH = 512 / V;
     const int lph_all = LPH * nh;
@@ -504,11 +510,20 @@ __global__ __launch_bounds__(512) void head2_wgrad_kernel(FrameGeo dout, FrameGe
     const long long npix = (long long)hid.n * hid.h * hid.w;
     const long long per = (npix + gridDim.x - 1) / gridDim.x;
     const long long p0 = (long long)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
+    float w[DG ? 8 : 1][V];
+    if constexpr (DG) {
+        const int k = ha.k[hd];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < V; ++i) w[j][i] = (active && j < k) ? ha.w2[hd][j * 512 + c0 + i] : 0.f;
+    }
     if (active && p0 + grp < p1) {
         long long p = p0 + grp;
         int n = (int)(p / ((long long)hid.h * hid.w));
         int rem = (int)(p - (long long)n * hid.h * hid.w);
         int py = rem / hid.w, px = rem - py * hid.w;
+        int nc = n, pyc = py, pxc = px;                                   // coordinates of the pixel being consumed (DG)
         // raw 16-byte chunks of three pixels ahead stay in flight (two loads each); converted when consumed
         constexpr int D = 3;
         u32x4 graw[D], ghi[D], hraw[D];                                   // ghi: channels 4..7 of an f32 slot
@@ -555,7 +570,33 @@ __global__ __launch_bounds__(512) void head2_wgrad_kernel(FrameGeo dout, FrameGe
 #pragma unroll
                         for (int i = 0; i < V / 2; ++i) acc[j][i] = g2 * (f32x2){h[2 * i], h[2 * i + 1]} + acc[j][i];
                     }
+                    if constexpr (DG) {                                   // same arithmetic and order as head2_dgrad_kernel
+                        float o[V];
+#pragma unroll
+                        for (int i = 0; i < V; ++i) {
+                            float a2 = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) a2 += gj[j] * w[j][i];
+                            o[i] = a2;
+                        }
+                        if (mask) {
+                            const unsigned char* mk = mask + (size_t)pc * mask_ld + hd * 512 + c0;
+                            unsigned char mb[V];
+                            if constexpr (V == 8) *(u32x2*)mb = *(const u32x2*)mk; else *(unsigned int*)mb = *(const unsigned int*)mk;
+#pragma unroll
+                            for (int i = 0; i < V; ++i) o[i] = mb[i] ? o[i] * 2.f : 0.f;
+                        } else if (use_hash) {
+#pragma unroll
+                            for (int q = 0; q < V / 4; ++q) {
+                                const unsigned kb = dbx_drop_bits4(drop_seed, (unsigned)pc, (unsigned)(hd * 512 + c0) / 4 + q);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) o[4 * q + i] = (kb >> i & 1u) ? o[4 * q + i] * 2.f : 0.f;
+                            }
+                        }
+                        store_vec<T>((T*)dhid.base + geo_pix(dhid, nc, pyc, pxc) + hd * 512 + c0, o);
+                    }
                 }
+                if constexpr (DG) { pxc += ppb; while (pxc >= hid.w) { pxc -= hid.w; if (++pyc == hid.h) { pyc = 0; ++nc; } } }
                 pc += ppb;
             }
         }
@@ -635,7 +676,8 @@ extern "C" int64_t dbx_head2_wgrad_scratch_bytes(int32_t nh, int32_t rows) {
 }
 template <typename T>
 static int head2_wgrad_t(const dbx_view* dout, const dbx_view* hid, const int32_t* k, int nh, float* const* dw, float* const* db,
-                         void* scratch, hipStream_t s) {
+                         void* scratch, hipStream_t s, const float* const* w2 = nullptr, const dbx_view* dhid = nullptr,
+                         const uint8_t* mask = nullptr, int mask_ld = 0, int use_hash = 0, unsigned drop_seed = 0) {
     VIEW_VEC_CHECK(T, hid, "head2_wgrad hid");
     DBX_REQUIRE(nh >= 1 && nh <= 4 && hid->c == 512 * nh && dout->c % nh == 0 && dout->c / nh >= 8, "head2_wgrad: nh in 1..4, hid of 512*nh channels, d_out of nh slots >= 8 channels");
     DBX_REQUIRE(dout->n == hid->n && dout->h == hid->h && dout->w == hid->w, "head2_wgrad: shape mismatch");
@@ -651,7 +693,18 @@ static int head2_wgrad_t(const dbx_view* dout, const dbx_view* hid, const int32_
     const int blocks = head2_wgrad_blocks(hid->n * hid->h);
     float* partial = (float*)scratch;
     float* bpartial = partial + (size_t)blocks * nh * 8 * 512;
-    hipLaunchKernelGGL(head2_wgrad_kernel<T>, dim3(blocks), dim3(threads), 0, s, make_geo<T>(dout), make_geo<T>(hid), nh, dout->c / nh, partial, bpartial);
+    Head2Args ha;
+    ha.nh = nh; ha.slot = dout->c / nh;
+    for (int i = 0; i < 4; ++i) { ha.w2[i] = (w2 && i < nh) ? w2[i] : nullptr; ha.k[i] = i < nh ? k[i] : 0; }
+    if (dhid) {
+        VIEW_VEC_CHECK(T, dhid, "head2_backward d_hid");
+        DBX_REQUIRE(w2 && dhid->c == 512 * nh && dout->n == dhid->n && dout->h == dhid->h && dout->w == dhid->w, "head2_backward: d_hid of 512*nh channels on the d_out grid");
+        for (int i = 0; i < nh; ++i) DBX_REQUIRE(w2[i], "head2_backward: null weight");
+        hipLaunchKernelGGL((head2_wgrad_kernel<T, true>), dim3(blocks), dim3(threads), 0, s, make_geo<T>(dout), make_geo<T>(hid), nh, dout->c / nh,
+                           partial, bpartial, ha, make_geo<T>(dhid), mask, mask_ld, use_hash, drop_seed);
+    } else
+        hipLaunchKernelGGL((head2_wgrad_kernel<T, false>), dim3(blocks), dim3(threads), 0, s, make_geo<T>(dout), make_geo<T>(hid), nh, dout->c / nh,
+                           partial, bpartial, ha, make_geo<T>(hid), (const unsigned char*)nullptr, 0, 0, 0u);
     DBX_LAUNCH_CHECK();
     const int total = nh * 8 * 512 + nh * 8;
     hipLaunchKernelGGL(head2_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, s, partial, bpartial, blocks, nh, o);
@@ -662,6 +715,15 @@ extern "C" int dbx_head2_wgrad(int32_t dtype, const dbx_view* d_out, const dbx_v
                                float* const* dw, float* const* db, void* scratch, void* stream) {
     if (!d_out || !hid || !k || !dw || !scratch) { dbx_set_error("head2_wgrad: null argument"); return DBX_ERR_ARG; }
     DBX_DISPATCH_DTYPE(dtype, head2_wgrad_t, d_out, hid, k, nh, dw, db, scratch, (hipStream_t)stream);
+}
+
+// Stage-2 heads backward in one pass: dbx_head2_wgrad + dbx_head2_dgrad (bitwise the same results as the two calls).
+extern "C" int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const float* const* w2, const int32_t* k,
+                                  int32_t nh, const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash,
+                                  uint32_t drop_seed, float* const* dw, float* const* db, void* scratch, void* stream) {
+    if (!d_out || !hid || !w2 || !k || !d_hid || !dw || !scratch) { dbx_set_error("head2_backward: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(dtype, head2_wgrad_t, d_out, hid, k, nh, dw, db, scratch, (hipStream_t)stream, w2, d_hid, dropmask, dropmask_ld,
+                       use_hash, (unsigned)drop_seed);
 }
 
 // ---------------------------------------------------------------------------------------------- multi-tensor weight packing

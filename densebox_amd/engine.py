@@ -709,22 +709,32 @@ class Engine:
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        def run_h2():
-            check(L.dbx_head2_wgrad(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_int32 * nh)(*[k for _, k in heads]), nh,
-                                    (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
-                                    ptr(self._h2_scratch), stream_ptr()))
+        w2s = [self._param('conv5_2_%s.weight' % st).detach() for st, _ in heads]      # fp32 [k,512,1,1]
+        ks = (C.c_int32 * nh)(*[k for _, k in heads])
+        h2_names = ['conv5_2_%s.weight' % st for st, _ in heads] + ['conv5_2_%s.bias' % st for st, _ in heads]
+        mask_p = C.c_void_p(P.mask_buf.data_ptr()) if (P.drop_active and not P.drop_hash) else None
+        hash_on, hash_seed = (1 if P.drop_hash else 0), (P.drop_seed if P.drop_hash else 0)
+        if side is not None:
+            def run_h2():
+                check(L.dbx_head2_wgrad(dt, C.byref(B['d_out'].view()), C.byref(hv), ks, nh,
+                                        (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
+                                        ptr(self._h2_scratch), stream_ptr()))
+                if sink is not None:
+                    sink.ready(h2_names)
+            on_side(run_h2)
+            check(L.dbx_head2_dgrad(dt, C.byref(B['d_out'].view()), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]), ks, nh,
+                                    C.byref(B['d_hid'].view()), mask_p, 512 * nh, hash_on, hash_seed, s))
+        else:       # one pass over the pixels: the d_hid write overlaps the hid read
+            check(L.dbx_head2_backward(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]), ks, nh,
+                                       C.byref(B['d_hid'].view()), mask_p, 512 * nh, hash_on, hash_seed,
+                                       (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
+                                       ptr(self._h2_scratch), s))
             if sink is not None:
-                sink.ready(['conv5_2_%s.weight' % st for st, _ in heads] + ['conv5_2_%s.bias' % st for st, _ in heads])
-        on_side(run_h2)
+                sink.ready(h2_names)
         if prof is not None:
             ev1.record()
             prof.append({'kernel': 'head2_wgrad_kernel<%s>' % ('f16', 'bf16', 'f32')[dt],
-                         'flops': 2.0 * hv.n * hv.h * hv.w * 512 * sum(k for _, k in heads), 'start': ev0, 'end': ev1})
-        w2s = [self._param('conv5_2_%s.weight' % st).detach() for st, _ in heads]      # fp32 [k,512,1,1]
-        check(L.dbx_head2_dgrad(dt, C.byref(B['d_out'].view()), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]),
-                                (C.c_int32 * nh)(*[k for _, k in heads]), nh, C.byref(B['d_hid'].view()),
-                                C.c_void_p(P.mask_buf.data_ptr()) if (P.drop_active and not P.drop_hash) else None, 512 * nh,
-                                1 if P.drop_hash else 0, P.drop_seed if P.drop_hash else 0, s))
+                         'flops': 2.0 * hv.n * hv.h * hv.w * 512 * sum(k for _, k in heads) * (1 if side is not None else 2), 'start': ev0, 'end': ev1})
         w1n = ['conv5_1_%s.weight' % st for st, _ in heads]
         b1n = ['conv5_1_%s.bias' % st for st, _ in heads]
         if sink is not None:           # the heads' conv5_1 gradients are adjacent in the flat buffer (grad_order)

@@ -136,6 +136,11 @@ int dbx_head2_dgrad(int32_t dtype, const dbx_view* d_out, const float* const* w2
 int64_t dbx_head2_wgrad_scratch_bytes(int32_t nh, int32_t rows);
 int dbx_head2_wgrad(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const int32_t* k, int32_t nh,
                     float* const* dw, float* const* db, void* scratch, void* stream);
+/* Both of the above in ONE pass over the pixels (the d_hid write overlaps the hid read); results are bitwise those of
+ * dbx_head2_wgrad followed by dbx_head2_dgrad.  scratch as for dbx_head2_wgrad. */
+int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const float* const* w2, const int32_t* k,
+                       int32_t nh, const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash,
+                       uint32_t drop_seed, float* const* dw, float* const* db, void* scratch, void* stream);
 
 /* eval-mode folding of one head, Conv1x1(768->512) -> Dropout(identity) -> Conv1x1(512->k), into a single 768->k map
  * (no non-linearity in between, DenseBox.py:158-162): w_out[k][768] = w2 w1, b_out[k] = w2 b1 + b2 (all fp32) */

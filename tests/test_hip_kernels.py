@@ -373,3 +373,44 @@ def test_forced_kernel_variants_in_subprocesses():
                            env=dict(os.environ, **env), timeout=1800)
         assert r.returncode == 0, (env, r.stdout[-3000:])
         assert ' passed' in r.stdout and 'skipped' not in r.stdout.splitlines()[-1], (env, r.stdout[-500:])
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16', 'f32'])
+@pytest.mark.parametrize('drop', ['none', 'hash', 'mask'])
+def test_head2_backward_fused_equals_separate_calls(dtn, drop):
+    """dbx_head2_backward (one pass: weight/bias gradients + data gradient) is bitwise dbx_head2_wgrad + dbx_head2_dgrad."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    ks = [1, 4, 4, 8]
+    nh, n, h, w = len(ks), 3, 11, 13
+    g = torch.Generator(device='cpu').manual_seed(5)
+    hid = torch.relu(torch.randn(n, 512 * nh, h, w, generator=g)).cuda()
+    dout = torch.zeros(n, 8 * nh, h, w)
+    for i, k in enumerate(ks):
+        dout[:, 8 * i:8 * i + k] = torch.randn(n, k, h, w, generator=g)
+    dout = dout.cuda()
+    w2 = [(torch.randn(k, 512, generator=g) * 0.05).cuda().contiguous() for k in ks]
+    fh, th, hv = framed(hid, 1, tdt)
+    fo, to, dv = framed(dout, 0, tdt)
+    mask = (torch.rand(n * h * w, 512 * nh, generator=g) < 0.5).to(torch.uint8).cuda() if drop == 'mask' else None
+    use_hash, seed = (1, 0xBEEF) if drop == 'hash' else (0, 0)
+    sc = torch.empty(L.dbx_head2_wgrad_scratch_bytes(nh, n * h), dtype=torch.uint8, device='cuda')
+    karr = (C.c_int32 * nh)(*ks)
+    wp = (C.c_void_p * nh)(*[t.data_ptr() for t in w2])
+
+    def outs():
+        fd, td, dhv = framed(torch.zeros(n, 512 * nh, h, w), 1, tdt)
+        dws = [torch.full((k, 512), 7.0, device='cuda') for k in ks]
+        dbs = [torch.full((k,), 7.0, device='cuda') for k in ks]
+        return fd, td, dhv, dws, dbs
+    fd1, td1, dhv1, dw1, db1 = outs()
+    check(L.dbx_head2_wgrad(dt, C.byref(dv), C.byref(hv), karr, nh, (C.c_void_p * nh)(*[t.data_ptr() for t in dw1]),
+                            (C.c_void_p * nh)(*[t.data_ptr() for t in db1]), ptr(sc), stream_ptr()))
+    check(L.dbx_head2_dgrad(dt, C.byref(dv), wp, karr, nh, C.byref(dhv1), ptr(mask), 512 * nh, use_hash, seed, stream_ptr()))
+    fd2, td2, dhv2, dw2, db2 = outs()
+    check(L.dbx_head2_backward(dt, C.byref(dv), C.byref(hv), wp, karr, nh, C.byref(dhv2), ptr(mask), 512 * nh, use_hash, seed,
+                               (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
+                               ptr(sc), stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(fd1, fd2) and float(td2.float().abs().sum()) > 0
+    assert all(torch.equal(a, b) for a, b in zip(dw1, dw2)) and all(torch.equal(a, b) for a, b in zip(db1, db2))
