@@ -109,8 +109,13 @@ def pmc_traffic(family):
         return None
     code = {'bf16': 'DF16b', 'f16': 'DF16_', 'f32': 'f'}[m.group(2)]
     ints = [v for v in m.group(3).split(',') if v]
+    name, want = m.group(1), ['Li%sE' % i for i in ints[-1:]]
+    if name in ('conv3x3_ws_kernel', 'conv1x1_ws_kernel'):
+        # the plan names the ws kernels by tile (256x256 / 512x128); the symbol carries <T, wave rows, kernel size>
+        want = ['Li%dELi%dE' % (1 if ints[:1] == ['256'] else 2, 3 if name == 'conv3x3_ws_kernel' else 1)]
+        name = 'conv3x3_ws_kernel'
     for k, v in doc.get('kernels', {}).items():
-        if m.group(1) in k and ('I' + code) in k and all(('Li%sE' % i) in k for i in ints[-1:]):
+        if name in k and ('I' + code) in k and all(w in k for w in want):
             return round(v['hbm_bytes_per_launch'])
     return None
 
