@@ -742,7 +742,18 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
 // b128 column reads) + 2 x 43 520 B.  (Four fat waves on 32x32x16 MFMAs -- 1.5x fewer LDS fragment bytes -- measured 40 % slower.)
 struct C64Geo { int tiles_x, tiles_y, ntiles, H, W; };
 
-template <typename T>
+//
+// POOL = true (dbx_conv_forward_pool: conv1_2 -> pool1, DenseBox.py:187): the 2x2/2 max pooling of the output happens in the
+// epilogue.  A wave then owns TWO tile rows x 16 pixels (rows 2(w>>1), 2(w>>1)+1; columns 16(w&1)..+15) instead of one row
+// x 32, so a pooling window is two accumulator fragments of one lane (vertical) and two neighbouring lanes (horizontal, one
+// DPP quad permute); the pooled map costs a quarter of the output's store bytes and the separate pooling pass -- which
+// re-read the whole 472 MB map at batch 64 -- disappears.  a.y2 is the pooled destination; EPI2_POOL_ONLY skips the full map.
+constexpr int EPI2_POOL = 1 << 20, EPI2_POOL_ONLY = 1 << 21;
+__device__ __forceinline__ float dpp_xor1(float v) {          // value of lane ^ 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+template <typename T, bool POOL>
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, const C64Geo tg) {
     static_assert(sizeof(T) == 2, "16-bit types");
     constexpr int TR = 8, TC = 32, HR = TR + 2, HC = TC + 2, HPX = HR * HC;      // 340 halo pixels of 128 B
@@ -800,7 +811,8 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, cons
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
-            const int p = (wave + t / 3) * HC + mi * 16 + fr + (t % 3);
+            const int p = POOL ? (2 * (wave >> 1) + mi + t / 3) * HC + (wave & 1) * 16 + fr + (t % 3)
+                               : (wave + t / 3) * HC + mi * 16 + fr + (t % 3);
             offX[t][mi] = p * 128 + ((g ^ dma_swz<128>(p)) << 4);
         }
     const int offW = fr * WROW + g * 16;
@@ -855,6 +867,50 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, cons
         // ---- epilogue: wave's tile row, pixel x0 + mi*16 + fr; lane holds couts cb + ni*16 + {0..3}
         const int n = tile / (tg.tiles_x * tg.tiles_y), r = tile - n * (tg.tiles_x * tg.tiles_y);
         const int ty = r / tg.tiles_x, tx = r - ty * tg.tiles_x;
+        if constexpr (POOL) {
+            const int oy = ty * TR + 2 * (wave >> 1), ox = tx * TC + (wave & 1) * 16 + fr;      // H, W even: rows oy, oy + 1 together
+            const bool ok = ox < tg.W;
+            if (oy < tg.H) {                                                     // wave-uniform
+                f32x4 v[4][2];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        f32x4 t = acc[ni][mi] + bias[ni];
+                        if (epi & DBX_EPI_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+                        v[ni][mi] = t;
+                    }
+                if (!(a.epi2 & EPI2_POOL_ONLY)) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        T* ypix = (T*)a.y + (size_t)((n * a.y_hp + oy + mi + a.y_pad) * a.y_wp + (ox + a.y_pad)) * (size_t)a.y_ld;
+#pragma unroll
+                        for (int ni = 0; ni < 4; ni += 2) {
+                            const u32x4 o = pair_exchange<T>(v[ni][mi], v[ni + 1][mi]);
+                            if (ok) *(u32x4*)(ypix + pair_cout_off(g, ni)) = o;
+                        }
+                    }
+                }
+                // rounding to T is monotonic: max of the f32 values, then rounded == max of the rounded values (dbx_maxpool2x2)
+                T* ppix = (T*)a.y2 + (size_t)((n * a.y2_hp + (oy >> 1) + a.y2_pad) * a.y2_wp + ((ox >> 1) + a.y2_pad)) * (size_t)a.y2_ld;
+#pragma unroll
+                for (int ni = 0; ni < 4; ni += 2) {
+                    f32x4 m[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        f32x4 t;
+                        t.x = fmaxf(v[ni + q][0].x, v[ni + q][1].x); t.y = fmaxf(v[ni + q][0].y, v[ni + q][1].y);
+                        t.z = fmaxf(v[ni + q][0].z, v[ni + q][1].z); t.w = fmaxf(v[ni + q][0].w, v[ni + q][1].w);
+                        t.x = fmaxf(t.x, dpp_xor1(t.x)); t.y = fmaxf(t.y, dpp_xor1(t.y));
+                        t.z = fmaxf(t.z, dpp_xor1(t.z)); t.w = fmaxf(t.w, dpp_xor1(t.w));
+                        m[q] = t;
+                    }
+                    const u32x4 o = pair_exchange<T>(m[0], m[1]);
+                    if (ok && !(fr & 1)) *(u32x4*)(ppix + pair_cout_off(g, ni)) = o;
+                }
+            }
+            continue;
+        }
         const int oy = ty * TR + wave;
         if (oy < tg.H) {                                                         // wave-uniform
 #pragma unroll
@@ -1062,14 +1118,14 @@ static int launch_conv_c8(const ConvArgs& a, int n, int h, int w, hipStream_t s)
     return DBX_OK;
 }
 
-template <typename T>
+template <typename T, bool POOL = false>
 static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         constexpr int smem = 64 * 1168 + 2 * (340 * 128 + 1024);
         static_assert(smem <= 160 * 1024, "LDS budget");
         static bool attr_set = false;
         if (!attr_set) {
-            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_kernel<T, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
         static int ncu = 0;
@@ -1081,7 +1137,7 @@ static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s
         C64Geo tg;
         tg.tiles_x = (w + 31) / 32; tg.tiles_y = (h + 7) / 8; tg.ntiles = n * tg.tiles_x * tg.tiles_y; tg.H = h; tg.W = w;
         const int grid = tg.ntiles < ncu ? tg.ntiles : ncu;                 // one persistent workgroup per CU
-        hipLaunchKernelGGL((conv3x3_c64_kernel<T>), dim3(grid), dim3(512), smem, s, a, tg);
+        hipLaunchKernelGGL((conv3x3_c64_kernel<T, POOL>), dim3(grid), dim3(512), smem, s, a, tg);
         DBX_LAUNCH_CHECK();
     }
     return DBX_OK;
@@ -1093,6 +1149,13 @@ static int ws_level() {              // DBX_WS=0 keeps the LDS band kernels on e
     return v;
 }
 static bool ws_enabled() { return ws_level() != 0; }
+// problems the pooled epilogue exists for: exactly the halo-tile kernel's (conv3x3_c64_kernel) with even output sizes
+template <typename T>
+static bool c64_pool_ok(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y) {
+    return sizeof(T) == 2 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 && d->cin_pad == 64 && d->cout_pad == 64 &&
+           y->c == 64 && x->c >= 64 && !(d->epilogue & ~(DBX_EPI_BIAS | DBX_EPI_RELU)) && y->h % 2 == 0 && y->w % 2 == 0 &&
+           x->h == y->h && x->w == y->w && x->n == y->n;
+}
 static int g_conv_variant_override = -1;   // set by in-tree lab programs that include this file (tools/band_lab.hip)
 static int conv_variant() {          // DBX_CONV_VARIANT=1 forces the register-staged v1 kernel everywhere (A/B testing)
     static int v = -1;
@@ -1155,7 +1218,17 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.epi = d->epilogue & ~DBX_CONV_WFRAG; a.dm_ld = dm_ld; a.drop_seed = d->drop_seed;
     a.y2 = nullptr; a.gate2 = nullptr; a.split_c = 0; a.epi2 = 0; a.cout_valid2 = 0;
     a.y2_hp = a.y2_wp = a.y2_ld = a.y2_pad = a.g2_hp = a.g2_wp = a.g2_ld = a.g2_pad = 0;
-    if (y2) {
+    if (y2 && (epi2 & EPI2_POOL)) {
+        // pooled second destination: the 64 -> 64 halo-tile kernel only (dbx_conv_pool_fusable)
+        DBX_REQUIRE(c64_pool_ok<T>(d, x, y), "conv pool: needs a 16-bit 3x3/pad 1 64 -> 64 layer on congruent frames with even H, W and a bias/ReLU epilogue");
+        DBX_REQUIRE(y2->n == y->n && y2->h == y->h / 2 && y2->w == y->w / 2 && y2->c == 64 && ((y2->c_off * ES) % 16) == 0 && (y2->ld * ES) % 16 == 0 &&
+                    ((y->c_off * ES) % 16) == 0 && (y->ld * ES) % 16 == 0, "conv pool: pooled view must be N x H/2 x W/2 x 64, 16-byte aligned");
+        a.y2 = (char*)y2->ptr + (size_t)y2->c_off * ES;
+        a.y2_hp = y2->h + 2 * y2->pad; a.y2_wp = y2->w + 2 * y2->pad; a.y2_ld = y2->ld; a.y2_pad = y2->pad;
+        a.epi2 = epi2;
+        if (plan) DBX_SELECT(DBX_K_C64, 256, 64, "conv3x3_c64_kernel", 0);
+        return launch_conv_c64<T, true>(a, x->n, x->h, x->w, s);
+    } else if (y2) {
         // split destination: 1x1 GEMM on the 256-wide DMA tiles only
         DBX_REQUIRE(sizeof(T) == 2 && d->kh == 1 && d->kw == 1 && !smallc && split_c > 0 && split_c % 256 == 0 && y->c == split_c &&
                     d->cout_pad % 256 == 0 && split_c + y2->c <= d->cout_pad && y2->c % 4 == 0 && y2->h == y->h && y2->w == y->w && y2->n == y->n &&
@@ -1313,6 +1386,24 @@ extern "C" int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x,
     if (!d || !x || !y || !y2 || !w_packed) { dbx_set_error("conv split: null argument"); return DBX_ERR_ARG; }
     if (d->dtype == DBX_F32) { dbx_set_error("conv split: 16-bit types only"); return DBX_ERR_DTYPE; }
     DBX_DISPATCH_DTYPE(d->dtype, conv_forward_t, d, x, w_packed, bias, y, gate, nullptr, 0, (hipStream_t)stream, y2, gate2, split_c, epilogue2);
+}
+
+template <typename T>
+static int conv_pool_ok_t(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y) { return c64_pool_ok<T>(d, x, y) ? 1 : 0; }
+extern "C" int dbx_conv_pool_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y) {
+    if (!d || !x || !y) return 0;
+    switch (d->dtype) {
+        case DBX_F16: return conv_pool_ok_t<_Float16>(d, x, y);
+        case DBX_BF16: return conv_pool_ok_t<__bf16>(d, x, y);
+        default: return 0;
+    }
+}
+extern "C" int dbx_conv_forward_pool(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
+                                     const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* stream) {
+    if (!d || !x || !y || !ypool || !w_packed) { dbx_set_error("conv pool: null argument"); return DBX_ERR_ARG; }
+    if (d->dtype == DBX_F32) { dbx_set_error("conv pool: 16-bit types only"); return DBX_ERR_DTYPE; }
+    DBX_DISPATCH_DTYPE(d->dtype, conv_forward_t, d, x, w_packed, bias, y, nullptr, nullptr, 0, (hipStream_t)stream, ypool, nullptr, 0,
+                       EPI2_POOL | (write_full ? 0 : EPI2_POOL_ONLY));
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing

@@ -466,8 +466,23 @@ class Engine:
                        RELU | (_lib.CONV_WFRAG if frag else 0), alg_ci=cin)
 
         conv3('conv1_1_1', 'x0', 'a11', 3, 64)
-        conv3('conv1_2_1', 'a11', 'a12', 64, 64)
-        check(L.dbx_maxpool2x2(dt, C.byref(B['a12'].view()), C.byref(B['p1'].view()), s))
+        d12 = ConvDesc(dt, 3, 3, 1, 64, 64, RELU, 0)
+        a11v, a12v, p1v = B['a11'].view(), B['a12'].view(), B['p1'].view()
+        if L.dbx_conv_pool_fusable(C.byref(d12), C.byref(a11v), C.byref(a12v)):
+            # conv1_2 + pool1 in one kernel; the full-resolution map is only kept when a backward pass will read it
+            prof = self.profile
+            if prof is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            check(L.dbx_conv_forward_pool(C.byref(d12), C.byref(a11v), ptr(self._w_fwd(dt, 'conv1_2_1', 64, 64, frag=False)),
+                                          ptr(self._bias(['conv1_2_1'], 64)), C.byref(a12v), C.byref(p1v), 1 if train else 0, s))
+            if prof is not None:
+                ev1.record()
+                prof.append({'kernel': self.conv_plan(dt, a11v, a12v, 3, 3, 1, 64, 64, RELU)[1],
+                             'flops': 2.0 * a12v.n * a12v.h * a12v.w * 9 * 64 * 64, 'start': ev0, 'end': ev1})
+        else:
+            conv3('conv1_2_1', 'a11', 'a12', 64, 64)
+            check(L.dbx_maxpool2x2(dt, C.byref(a12v), C.byref(p1v), s))
         conv3('conv2_1_1', 'p1', 'a21', 64, 128)
         conv3('conv2_2_1', 'a21', 'a22', 128, 128)
         check(L.dbx_maxpool2x2(dt, C.byref(B['a22'].view()), C.byref(B['p2'].view()), s))

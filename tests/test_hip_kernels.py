@@ -414,3 +414,52 @@ def test_head2_backward_fused_equals_separate_calls(dtn, drop):
     torch.cuda.synchronize()
     assert torch.equal(fd1, fd2) and float(td2.float().abs().sum()) > 0
     assert all(torch.equal(a, b) for a, b in zip(dw1, dw2)) and all(torch.equal(a, b) for a, b in zip(db1, db2))
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(3, 40, 72), (2, 18, 34), (16, 64, 128)])
+def test_conv_forward_pool_equals_conv_then_maxpool(shape, dtn):
+    """dbx_conv_forward_pool (conv1_2 + pool1 in one kernel): the pooled map is bitwise dbx_maxpool2x2 of the full map it
+    writes; where dbx_conv_forward runs the same halo-tile kernel (>= 256 tiles) the full map is bitwise equal too, elsewhere
+    equal up to summation order; write_full = 0 leaves the full map untouched."""
+    n, h, w = shape
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    g = torch.Generator(device='cpu').manual_seed(h * w)
+    x = torch.randn(n, 64, h, w, generator=g).cuda()
+    wt = (torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).cuda()
+    b = torch.randn(64, generator=g).cuda()
+    fx, tx, xv = framed(x, 1, tdt)
+    wp = pack(L, dt, wt, 64, 64)
+    d = ConvDesc(dt, 3, 3, 1, 64, 64, _lib.EPI_BIAS | _lib.EPI_RELU)
+    fy, ty, yv = framed(torch.zeros(n, 64, h, w), 1, tdt)
+    fp, tp, pv = framed(torch.zeros(n, 64, h // 2, w // 2), 1, tdt)
+    assert L.dbx_conv_pool_fusable(C.byref(d), C.byref(xv), C.byref(yv)) == 1
+    check(L.dbx_conv_forward(C.byref(d), C.byref(xv), ptr(wp), ptr(b), C.byref(yv), None, None, 0, stream_ptr()))
+    check(L.dbx_maxpool2x2(dt, C.byref(yv), C.byref(pv), stream_ptr()))
+    fy2, ty2, yv2 = framed(torch.zeros(n, 64, h, w), 1, tdt)
+    fp2, tp2, pv2 = framed(torch.zeros(n, 64, h // 2, w // 2), 1, tdt)
+    check(L.dbx_conv_forward_pool(C.byref(d), C.byref(xv), ptr(wp), ptr(b), C.byref(yv2), C.byref(pv2), 1, stream_ptr()))
+    fp4, tp4, pv4 = framed(torch.zeros(n, 64, h // 2, w // 2), 1, tdt)
+    check(L.dbx_maxpool2x2(dt, C.byref(yv2), C.byref(pv4), stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(fp4, fp2) and float(tp2.float().abs().sum()) > 0
+    plan = _lib.ConvPlan()
+    check(L.dbx_conv_plan(C.byref(d), C.byref(xv), C.byref(yv), C.byref(plan)))
+    if plan.kernel == _lib.K_C64:
+        assert torch.equal(fy, fy2) and torch.equal(fp, fp2)
+    else:
+        assert (ty.float() - ty2.float()).abs().max().item() <= (2e-2 if dtn == 'bf16' else 3e-3) * (1 + ty.float().abs().max().item())
+    assert (n, h, w) != (16, 64, 128) or plan.kernel == _lib.K_C64
+    ref = F.max_pool2d(F.relu(F.conv2d(x.to(tdt).float(), wt.to(tdt).float(), b, padding=1)), 2)
+    got = tp2[:, 1:1 + h // 2, 1:1 + w // 2].permute(0, 3, 1, 2).float()
+    tol = 2e-2 if dtn == 'bf16' else 3e-3
+    assert torch.allclose(got, ref, rtol=tol, atol=tol)
+    fy3, ty3, yv3 = framed(torch.zeros(n, 64, h, w), 1, tdt)
+    fp3, tp3, pv3 = framed(torch.zeros(n, 64, h // 2, w // 2), 1, tdt)
+    check(L.dbx_conv_forward_pool(C.byref(d), C.byref(xv), ptr(wp), ptr(b), C.byref(yv3), C.byref(pv3), 0, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(fp2, fp3) and float(fy3.float().abs().sum()) == 0
+    # odd sizes: no fused path (the caller runs conv + maxpool)
+    fo, to, ov = framed(torch.zeros(n, 64, h + 1, w), 1, tdt)
+    assert L.dbx_conv_pool_fusable(C.byref(d), C.byref(ov), C.byref(ov)) == 0
