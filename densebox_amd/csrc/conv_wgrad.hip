@@ -14,6 +14,7 @@
 // also accumulate the bias gradient db[co] = sum_q dz[q][co] from the tiles they stream anyway.
 #include "common.hpp"
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef short short4v __attribute__((ext_vector_type(4)));
 
@@ -926,6 +927,22 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
 extern "C" int64_t dbx_conv_wgrad_scratch_bytes(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw) {
     const WgradPlan p = wgrad_plan(dtype, dz, x, kh, kw);
     return ((int64_t)p.splits * p.co_pad * p.taps * p.ci_pad + (int64_t)p.splits * p.co_pad) * 4 + 256;
+}
+
+// The kernel wgrad_t launches for this problem (one selection rule: wgrad_plan), for callers that label profiles.
+extern "C" int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, char* name, int32_t name_len,
+                                   int32_t* splits) {
+    if (!dz || !x || !name || name_len < 32) { dbx_set_error("wgrad plan: null argument / short name buffer"); return DBX_ERR_ARG; }
+    if (dtype != DBX_F16 && dtype != DBX_BF16 && dtype != DBX_F32) { dbx_set_error("bad dtype %d", (int)dtype); return DBX_ERR_DTYPE; }
+    const WgradPlan p = wgrad_plan(dtype, dz, x, kh, kw);
+    const char* tn = dtype == DBX_F32 ? "f32" : (dtype == DBX_F16 ? "f16" : "bf16");
+    if (p.c8) snprintf(name, name_len, "wgrad3x3_c8_kernel<%s>", tn);
+    else if (p.alltaps) snprintf(name, name_len, "wgrad3x3_kernel<%s>", tn);
+    else if (p.row3) snprintf(name, name_len, "wgrad_row3_kernel<%s>", tn);
+    else if (p.wide) snprintf(name, name_len, "wgrad_wide_kernel<%s>", tn);
+    else snprintf(name, name_len, "wgrad_kernel<%s,%d,%d>", tn, p.bmc, p.bnc);
+    if (splits) *splits = p.splits;
+    return DBX_OK;
 }
 
 template <typename T>

@@ -613,14 +613,9 @@ class Engine:
                                     ptr(self._wg_scratch), accumulate, stream_ptr()))
         if prof is not None:
             ev1.record()
-            big = dz.c > 64 and x.c > 64
-            tn = ('f16', 'bf16', 'f32')[dt]
-            if dt != _lib.F32 and kh == 3 and kw == 3 and dz.c <= 128 and x.c <= 128:
-                name = ('wgrad3x3_c8_kernel<%s>' if (x.c * _lib.ESIZE[dt] == 16 and dz.c == 64) else 'wgrad3x3_kernel<%s>') % tn
-            elif dt != _lib.F32 and kh == 3 and kw == 3 and dz.c % 128 == 0 and x.c % 128 == 0:
-                name = 'wgrad_row3_kernel<%s>' % tn
-            else:
-                name = 'wgrad_kernel<%s,%s>' % (tn, '128,128' if big else '64,64')
+            buf = C.create_string_buffer(64)                      # the library's own choice (dbx_conv_wgrad_plan)
+            check(self.L.dbx_conv_wgrad_plan(dt, C.byref(dz), C.byref(x), kh, kw, buf, 64, None))
+            name = buf.value.decode()
             prof.append({'kernel': name, 'flops': 2.0 * dz.n * dz.h * dz.w * kh * kw * ci * co, 'start': ev0, 'end': ev1})
 
     def backward_raw(self, grad_outs):

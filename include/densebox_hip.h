@@ -166,6 +166,10 @@ int64_t dbx_conv_wgrad_scratch_bytes(int32_t dtype, const dbx_view* dz, const db
  * db may be NULL.  accumulate != 0 adds into dw/db instead of overwriting. */
 int dbx_conv_wgrad(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, int32_t cpad,
                    int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch, int32_t accumulate, void* stream);
+/* The kernel dbx_conv_wgrad runs for this problem ("wgrad_row3_kernel<bf16>" ...) and its split-K factor: the library's own
+ * selection, for profile labels (no caller-side copy of the rule).  name_len >= 32. */
+int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, char* name, int32_t name_len,
+                        int32_t* splits);
 
 /* ------------------------------------------------------------------ layout / pooling / resampling
  * nchw_to_framed: network input X (DenseBox.py:185) fp32 NCHW -> framed NHWC compute dtype (channels padded with 0).

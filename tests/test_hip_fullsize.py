@@ -63,14 +63,15 @@ def _train_step(net, x, bbox, vert, lab, rn, lrn, batch_global, p_global):
     return float(loss.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
 
 
-def test_batch64_training_step_repeatable_and_shard_additive():
-    """configs[2]/[3]: full fwd/bwd with landmark heads at batch 64.  (1) Two runs from the same state are bit-identical
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+def test_batch64_training_step_repeatable_and_shard_additive(dtype):
+    """configs[2] (f16) / configs[3] (bf16): full fwd/bwd with landmark heads at batch 64.  (1) Two runs from the same state are bit-identical
     (fixed-order split-K, no atomics).  (2) The loss is a SUM over patches and mining uses the global constants, so four
     shards of 16 with the global (batch, positive) counts add up to the batch-64 loss and gradients (fp32 round-off of a
     different summation order only) -- the property data-parallel training relies on."""
     from densebox_amd import labels as LB
     kind = 'DenseBoxLMLOC'
-    net = _net(kind, 'bf16', train=True)
+    net = _net(kind, dtype, train=True)
     for m in net.modules():
         if isinstance(m, torch.nn.Dropout):
             m.p = 0.0                                   # shards must see the same function
