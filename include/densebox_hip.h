@@ -266,6 +266,17 @@ int dbx_perspective_matrix(const float* src_xy, const float* dst_xy, double* m9)
 int dbx_warp_perspective_u8(const uint8_t* src, int32_t sh, int32_t sw, int32_t c, const double* m9, uint8_t* dst,
                             int32_t dh, int32_t dw, void* stream);
 
+/* ---- data-parallel gradient exchange (new capability; the reference is single-GPU) ----
+ * One process per GPU.  Rank 0 makes a 128-byte id (dbx_dp_unique_id) and hands it to the other ranks by any host channel;
+ * every rank calls dbx_dp_init with its HIP device current; after each backward, dbx_dp_allreduce_sum_f32 sums the flat fp32
+ * gradient buffer (or a bucket of it) over the ranks in place on `stream` -- SUM without division, because the reference
+ * loss is a sum over the batch (DenseBox.py:2917).  RCCL over xGMI, resolved by dlopen at first use; the Python front end
+ * (densebox_amd/dist.py) drives the same collectives through torch.distributed's "nccl" backend instead. */
+int dbx_dp_unique_id(void* id128);
+int dbx_dp_init(const void* id128, int32_t rank, int32_t world, void** comm);
+int dbx_dp_allreduce_sum_f32(void* comm, float* buf, int64_t n, void* stream);
+int dbx_dp_destroy(void* comm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,3 +66,28 @@ def test_rccl_world_of_one_step_equals_plain_step():
         assert all(p.grad is not None for k, p in b.named_parameters() if k in ga)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_c_abi_dp_entry_points_world_of_one():
+    """dbx_dp_*: the C ABI's own RCCL path (for callers without torch.distributed): id -> communicator -> in-place SUM
+    all-reduce of a flat fp32 gradient buffer (identity in a world of one) -> destroy."""
+    import ctypes as C
+    import torch
+    from densebox_amd import _lib
+    from densebox_amd._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    torch.cuda.set_device(0)
+    ident = C.create_string_buffer(128)
+    check(L.dbx_dp_unique_id(ident))
+    comm = C.c_void_p()
+    check(L.dbx_dp_init(ident, 0, 1, C.byref(comm)))
+    assert comm.value
+    g = torch.randn(1 << 20, device='cuda')
+    ref = g.clone()
+    for lo in range(0, g.numel(), 1 << 18):                                    # bucketed, like the reducer
+        check(L.dbx_dp_allreduce_sum_f32(comm, C.c_void_p(g.data_ptr() + 4 * lo), 1 << 18, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    assert L.dbx_dp_init(ident, 1, 1, C.byref(C.c_void_p())) != 0             # rank out of range: error, not a hang
+    check(L.dbx_dp_destroy(comm))
