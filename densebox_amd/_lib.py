@@ -64,6 +64,9 @@ SIGNATURES = {
     'dbx_dp_init': (C.c_int, [_VP, _I32, _I32, C.POINTER(C.c_void_p)]),
     'dbx_dp_allreduce_sum_f32': (C.c_int, [_VP, _VP, _I64, _VP]),
     'dbx_dp_destroy': (C.c_int, [_VP]),
+    'dbx_conv_dgrad_wgrad1_scratch_bytes': (_I64, []),
+    'dbx_conv_dgrad_wgrad1_fusable': (C.c_int, [_PC, _PV, _PV, _PV]),
+    'dbx_conv_dgrad_wgrad1': (C.c_int, [_PC, _PV, _VP, _PV, _PV, _I32, _VP, _VP, _VP, _I32, _VP]),
     'dbx_conv_pool_fusable': (C.c_int, [_PC, _PV, _PV]),
     'dbx_conv_forward_pool': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _I32, _VP]),
     'dbx_pack_weight': (C.c_int, [_I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),

@@ -740,7 +740,8 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
 // compute of the current one; ONE barrier per tile, none inside its 18 K steps.  Wave w owns tile row w: 32 pixels x 64
 // couts, 2 x 4 accumulator fragments, 144 MFMAs per tile.  LDS: 64 x 1168 B weights (rows padded by 16 B: conflict-free
 // b128 column reads) + 2 x 43 520 B.  (Four fat waves on 32x32x16 MFMAs -- 1.5x fewer LDS fragment bytes -- measured 40 % slower.)
-struct C64Geo { int tiles_x, tiles_y, ntiles, H, W; };
+typedef short short4v __attribute__((ext_vector_type(4)));
+struct C64Geo { int tiles_x, tiles_y, ntiles, H, W; const char* x0; int x0_ld; float* partial; float* bpartial; };   // x0 .. : WG1 variant
 
 //
 // POOL = true (dbx_conv_forward_pool: conv1_2 -> pool1, DenseBox.py:187): the 2x2/2 max pooling of the output happens in the
@@ -753,9 +754,20 @@ __device__ __forceinline__ float dpp_xor1(float v) {          // value of lane ^
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
 
-template <typename T, bool POOL>
+//
+// WG1 = true (dbx_conv_dgrad_wgrad1: conv1_2's data gradient with conv1_1's WEIGHT gradient folded in, DenseBox.py:185-186
+// backwards): the tile of d(conv1_1 output) this kernel has just computed (gated by conv1_1's ReLU) is the dz operand of
+// conv1_1's weight gradient and of nothing else, so instead of writing the 472 MB map for a second kernel to re-read, every
+// wave rounds its 32-pixel x 64-channel row to T, parks it in the halo buffer it has just finished with, and contracts it
+// against the matching pixels of the 8-channel network input (a 10 x 34 halo tile of 16-byte pixels staged next to it) with
+// 20 more MFMAs: dW1[co][(tap, c)] += sum_px d[px][co] * x0[px + tap][c], (tap, c) as five 16-column fragments exactly as in
+// wgrad3x3_c8_kernel; the unused tenth tap reads a row holding 1.0 in channel 0, so its column IS the bias gradient.  The 80
+// accumulator registers live across the persistent workgroup's tiles; at the end the eight waves are summed in a fixed
+// order through LDS and each workgroup writes one [64][9][8] slab for wgrad_reduce_kernel.  Nothing is written to a.y.
+template <typename T, bool POOL, bool WG1 = false>
 __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, const C64Geo tg) {
     static_assert(sizeof(T) == 2, "16-bit types");
+    static_assert(!(POOL && WG1), "one epilogue variant at a time");
     constexpr int TR = 8, TC = 32, HR = TR + 2, HC = TC + 2, HPX = HR * HC;      // 340 halo pixels of 128 B
     constexpr int WROW = 1152 + 16, W_BYTES = 64 * WROW, IN_BYTES = HPX * 128;
     constexpr int PIECES = (HPX + 7) / 8;                                         // 1-KiB pieces (8 pixels): 43
@@ -817,9 +829,18 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, cons
         }
     const int offW = fr * WROW + g * 16;
 
+    // WG1: thread t < 340 fetches halo pixel t of the network-input tile; 4 x 5 persistent weight-gradient fragments
+    const int x0r = tid / HC, x0c = tid - (tid / HC) * HC;
+    f32x4 wacc[WG1 ? 4 : 1][WG1 ? 5 : 1];
+#pragma unroll
+    for (int i = 0; i < (WG1 ? 4 : 1); ++i)
+#pragma unroll
+        for (int f = 0; f < (WG1 ? 5 : 1); ++f) wacc[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    u32x4 x0reg = {0u, 0u, 0u, 0u};
+
     const int first = blockIdx.x, stride = gridDim.x;
-    if (first >= tg.ntiles) return;
-    issue(first, 0);
+    if (first >= tg.ntiles && !WG1) return;
+    if (first < tg.ntiles) issue(first, 0);
     const int cb = (lane >> 4) * 4;
     const int epi = a.epi;
     f32x4 bias[4];
@@ -830,6 +851,14 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, cons
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // this tile's halo (issued one tile ago) + older stores
         __builtin_amdgcn_s_barrier();                                             // everyone's pieces landed; everyone left the other buffer
         if (tile + stride < tg.ntiles) issue(tile + stride, buf ^ 1);
+        if constexpr (WG1) {
+            if (tid < HPX) {
+                const int n0 = tile / (tg.tiles_x * tg.tiles_y), r0 = tile - n0 * (tg.tiles_x * tg.tiles_y);
+                const int ty0 = r0 / tg.tiles_x, tx0 = r0 - ty0 * tg.tiles_x;
+                int fy = ty0 * TR + x0r; fy = fy < a.x_hp ? fy : a.x_hp - 1;
+                x0reg = *(const u32x4*)(tg.x0 + ((size_t)(n0 * a.x_hp + fy) * a.x_wp + (tx0 * TC + x0c)) * (size_t)(tg.x0_ld * 2));
+            }
+        }
         const char* Xb = In + buf * (IN_BYTES + 1024);
         f32x4 acc[4][2];
 #pragma unroll
@@ -867,6 +896,71 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, cons
         // ---- epilogue: wave's tile row, pixel x0 + mi*16 + fr; lane holds couts cb + ni*16 + {0..3}
         const int n = tile / (tg.tiles_x * tg.tiles_y), r = tile - n * (tg.tiles_x * tg.tiles_y);
         const int ty = r / tg.tiles_x, tx = r - ty * tg.tiles_x;
+        if constexpr (WG1) {
+            // ReLU gate of conv1_1's output in the exchanged layout (one 16-byte load per lane and fragment pair), issued before
+            // the barrier so that its latency overlaps the other waves' last MFMAs
+            const int oy = ty * TR + wave;
+            u32x4 gch[2][2];
+            bool okp[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int ox = tx * TC + mi * 16 + fr;
+                okp[mi] = oy < tg.H && ox < tg.W;
+                const T* gpix = (const T*)a.gate + (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + (ox + a.g_pad)) * (size_t)a.g_ld;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    gch[mi][q] = okp[mi] ? *(const u32x4*)(gpix + pair_cout_off(g, 2 * q)) : (u32x4){0u, 0u, 0u, 0u};
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                        // every wave has left this halo buffer
+            char* Dw = In + buf * (IN_BYTES + 1024) + wave * 4096;               // this wave's row: [32 px][64 ch] of T, swizzled
+            char* X0s = In + buf * (IN_BYTES + 1024) + 32768;                    // [340 halo px][8 ch] + the "ones" row
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int px = mi * 16 + fr;
+#pragma unroll
+                for (int ni = 0; ni < 4; ni += 2) {
+                    // all lanes: 8 consecutive channels of pixel fr; a zero gate chunk (pixels outside the image) clears them
+                    const u32x4 o = gate_packed16(pair_exchange<T>(acc[ni][mi], acc[ni + 1][mi]), gch[mi][ni >> 1]);
+                    *(u32x4*)(Dw + px * 128 + ((pair_cout_off(g, ni) * 2) ^ ((((px >> 1) & 1) << 5) | (((px >> 3) & 1) << 6)))) = o;
+                }
+            }
+            if (tid < HPX) *(u32x4*)(X0s + tid * 16) = x0reg;
+            if (tid == HPX) {                                                     // row 340: 1.0 in channel 0 (bias-gradient column)
+                T one[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) one[i] = from_f32<T>(i == 0 ? 1.f : 0.f);
+                *(u32x4*)(X0s + HPX * 16) = *(const u32x4*)one;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // transpose-read lane roles as in wgrad3x3_c8_kernel: lane L of a 16-lane group supplies row (L>>2), columns (L&3)*4..+3
+            const int rsub = (lane & 15) >> 2, cq = lane & 3;
+            auto trd = [&](const char* p) {
+                return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
+            };
+            u32x4 af[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int cbyte = ni * 32 + cq * 8, ra = 8 * g + rsub, rb = ra + 4;
+                const u32x2 lo = trd(Dw + ra * 128 + (cbyte ^ ((((ra >> 1) & 1) << 5) | (((ra >> 3) & 1) << 6))));
+                const u32x2 hi = trd(Dw + rb * 128 + (cbyte ^ ((((rb >> 1) & 1) << 5) | (((rb >> 3) & 1) << 6))));
+                af[ni] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+            }
+#pragma unroll
+            for (int f = 0; f < 5; ++f) {
+                const int tap = 2 * f + (cq >> 1);
+                const bool dead = tap >= 9;                                       // the tenth "tap": the ones row, every K
+                const int ky = tap / 3, kx = tap - ky * 3;
+                const int base = dead ? HPX * 16 + (cq & 1) * 8 : ((wave + ky) * HC + kx) * 16 + (cq & 1) * 8;
+                const int r0 = dead ? 0 : (8 * g + rsub) * 16, r1 = dead ? 0 : (8 * g + 4 + rsub) * 16;
+                const u32x2 lo = trd(X0s + base + r0), hi = trd(X0s + base + r1);
+                const u32x4 bf = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) Mma<T>::run(af[ni], bf, wacc[ni][f]);
+            }
+            continue;
+        }
         if constexpr (POOL) {
             const int oy = ty * TR + 2 * (wave >> 1), ox = tx * TC + (wave & 1) * 16 + fr;      // H, W even: rows oy, oy + 1 together
             const bool ok = ox < tg.W;
@@ -940,6 +1034,47 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, cons
                     if (ok) *(u32x4*)(ypix + pair_cout_off(g, ni)) = o;
                 }
             }
+        }
+    }
+    if constexpr (WG1) {
+        // fixed-order sum of the eight waves' fragments through LDS (80 KB at a time), then one slab per workgroup:
+        // [64 co][9 taps][8 ci] + the bias column; D layout: lane holds rows (couts) 4 g + r of column lane & 15
+        __syncthreads();
+        float* red = (float*)smem;
+#pragma unroll
+        for (int half = 4; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int f = 0; f < 5; ++f) *(f32x4*)(red + (((wave - half) * 20 + ni * 5 + f) * 64 + lane) * 4) = wacc[ni][f];
+            }
+            __syncthreads();
+            if (wave < half) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int f = 0; f < 5; ++f) wacc[ni][f] += *(const f32x4*)(red + ((wave * 20 + ni * 5 + f) * 64 + lane) * 4);
+            }
+            __syncthreads();
+        }
+        if (wave == 0) {
+            float* P = tg.partial + (size_t)blockIdx.x * 64 * 9 * 8;
+            const int col = lane & 15;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int f = 0; f < 5; ++f) {
+                    const int tap = 2 * f + (col >> 3), co_b = ni * 16 + (lane >> 4) * 4;
+                    const float v[4] = {wacc[ni][f].x, wacc[ni][f].y, wacc[ni][f].z, wacc[ni][f].w};
+                    if (tap < 9) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) P[((size_t)(co_b + r) * 9 + tap) * 8 + (col & 7)] = v[r];
+                    } else if (col == 8 && tg.bpartial) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tg.bpartial[(size_t)blockIdx.x * 64 + co_b + r] = v[r];
+                    }
+                }
         }
     }
 }
@@ -1118,14 +1253,19 @@ static int launch_conv_c8(const ConvArgs& a, int n, int h, int w, hipStream_t s)
     return DBX_OK;
 }
 
-template <typename T, bool POOL = false>
-static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s) {
+static int c64_wg1_slabs() {         // workgroups (= partial slabs) of the fused dgrad + weight-gradient launch: one per CU
+    static int n = 0;
+    if (!n) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+    return n;
+}
+template <typename T, bool POOL = false, bool WG1 = false>
+static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s, const C64Geo* extra = nullptr) {
     if constexpr (sizeof(T) == 2) {
         constexpr int smem = 64 * 1168 + 2 * (340 * 128 + 1024);
         static_assert(smem <= 160 * 1024, "LDS budget");
         static bool attr_set = false;
         if (!attr_set) {
-            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_kernel<T, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_kernel<T, POOL, WG1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
         static int ncu = 0;
@@ -1135,9 +1275,12 @@ static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s
             DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         }
         C64Geo tg;
+        tg.x0 = nullptr; tg.x0_ld = 0; tg.partial = nullptr; tg.bpartial = nullptr;
+        if (extra) tg = *extra;
         tg.tiles_x = (w + 31) / 32; tg.tiles_y = (h + 7) / 8; tg.ntiles = n * tg.tiles_x * tg.tiles_y; tg.H = h; tg.W = w;
-        const int grid = tg.ntiles < ncu ? tg.ntiles : ncu;                 // one persistent workgroup per CU
-        hipLaunchKernelGGL((conv3x3_c64_kernel<T, POOL>), dim3(grid), dim3(512), smem, s, a, tg);
+        // one persistent workgroup per CU (the weight-gradient variant: always all of them, every slab gets written)
+        const int grid = WG1 ? c64_wg1_slabs() : (tg.ntiles < ncu ? tg.ntiles : ncu);
+        hipLaunchKernelGGL((conv3x3_c64_kernel<T, POOL, WG1>), dim3(grid), dim3(512), smem, s, a, tg);
         DBX_LAUNCH_CHECK();
     }
     return DBX_OK;
@@ -1386,6 +1529,59 @@ extern "C" int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x,
     if (!d || !x || !y || !y2 || !w_packed) { dbx_set_error("conv split: null argument"); return DBX_ERR_ARG; }
     if (d->dtype == DBX_F32) { dbx_set_error("conv split: 16-bit types only"); return DBX_ERR_DTYPE; }
     DBX_DISPATCH_DTYPE(d->dtype, conv_forward_t, d, x, w_packed, bias, y, gate, nullptr, 0, (hipStream_t)stream, y2, gate2, split_c, epilogue2);
+}
+
+// conv1_2 data gradient + conv1_1 weight gradient in one launch (conv3x3_c64_kernel<T, false, true>)
+int dbx_internal_wgrad_reduce(const float* partial, const float* bpartial, int splits, int co, int ci, int taps, int co_pad, int ci_pad,
+                              float* dw, float* db, int accumulate, hipStream_t s);           // conv_wgrad.hip
+template <typename T>
+static bool c64_wg1_ok(const dbx_conv_desc* d, const dbx_view* dz, const dbx_view* gate, const dbx_view* x0) {
+    return sizeof(T) == 2 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && dz->pad == 1 && d->cin_pad == 64 && d->cout_pad == 64 &&
+           dz->c >= 64 && (d->epilogue & ~DBX_CONV_WFRAG) == DBX_EPI_GATE && gate && gate->n == dz->n && gate->h == dz->h && gate->w == dz->w &&
+           gate->c >= 64 && x0 && x0->n == dz->n && x0->h == dz->h && x0->w == dz->w && x0->pad == 1 && x0->c * sizeof(T) == 16 &&
+           x0->ld == x0->c && x0->c_off == 0 && ((size_t)x0->ptr % 16) == 0;
+}
+template <typename T>
+static int conv_dgrad_wgrad1_t(const dbx_conv_desc* d, const dbx_view* dz, const void* w, const dbx_view* gate, const dbx_view* x0, int ci,
+                               float* dw, float* db, void* scratch, int accumulate, hipStream_t s) {
+    constexpr int ES = sizeof(T);
+    DBX_REQUIRE(c64_wg1_ok<T>(d, dz, gate, x0), "dgrad+wgrad1: needs a 16-bit 3x3/pad 1 64 -> 64 gated data gradient on congruent frames and an 8-channel framed input");
+    DBX_REQUIRE(ci >= 1 && ci <= 8 && dw && scratch, "dgrad+wgrad1: 1..8 real input channels, dw and scratch required");
+    DBX_REQUIRE(((size_t)dz->ptr % 16) == 0 && (dz->ld * ES) % 16 == 0 && (dz->c_off * ES) % 16 == 0 && (gate->c_off * ES) % 16 == 0 && (gate->ld * ES) % 16 == 0 && ((size_t)gate->ptr % 16) == 0,
+                "dgrad+wgrad1: 16-byte alignment of dz and gate");
+    ConvArgs a;
+    memset(&a, 0, sizeof a);
+    a.x = (const char*)dz->ptr + (size_t)dz->c_off * ES;
+    a.w = (const char*)w;
+    a.gate = (const char*)gate->ptr + (size_t)gate->c_off * ES;
+    a.M = dz->n * dz->h * dz->w; a.HoWo = dz->h * dz->w; a.Wo = dz->w;
+    a.x_hp = dz->h + 2; a.x_wp = dz->w + 2; a.x_ld = dz->ld; a.x_org = 0;
+    a.g_hp = gate->h + 2 * gate->pad; a.g_wp = gate->w + 2 * gate->pad; a.g_ld = gate->ld; a.g_pad = gate->pad;
+    a.kw = 3; a.ntaps = 9; a.cpt = 8; a.ktot_bytes = 1152; a.ksteps = 9; a.cout_valid = 64; a.ntile_n = 1; a.epi = DBX_EPI_GATE;
+    C64Geo tg;
+    memset(&tg, 0, sizeof tg);
+    const int slabs = c64_wg1_slabs();
+    tg.x0 = (const char*)x0->ptr; tg.x0_ld = x0->ld;
+    tg.partial = (float*)scratch;
+    tg.bpartial = db ? (float*)scratch + (size_t)slabs * 64 * 9 * 8 : nullptr;
+    const int rc = launch_conv_c64<T, false, true>(a, dz->n, dz->h, dz->w, s, &tg);
+    if (rc != DBX_OK) return rc;
+    return dbx_internal_wgrad_reduce(tg.partial, tg.bpartial, slabs, 64, ci, 9, 64, 8, dw, db, accumulate, s);
+}
+extern "C" int64_t dbx_conv_dgrad_wgrad1_scratch_bytes(void) { return ((int64_t)c64_wg1_slabs() * (64 * 9 * 8 + 64)) * 4 + 256; }
+extern "C" int dbx_conv_dgrad_wgrad1_fusable(const dbx_conv_desc* d, const dbx_view* dz, const dbx_view* gate, const dbx_view* x0) {
+    if (!d || !dz || !gate || !x0) return 0;
+    switch (d->dtype) {
+        case DBX_F16: return c64_wg1_ok<_Float16>(d, dz, gate, x0) ? 1 : 0;
+        case DBX_BF16: return c64_wg1_ok<__bf16>(d, dz, gate, x0) ? 1 : 0;
+        default: return 0;
+    }
+}
+extern "C" int dbx_conv_dgrad_wgrad1(const dbx_conv_desc* d, const dbx_view* dz, const void* w_packed, const dbx_view* gate, const dbx_view* x0,
+                                     int32_t ci, float* dw_oihw, float* db, void* scratch, int32_t accumulate, void* stream) {
+    if (!d || !dz || !w_packed || !gate || !x0) { dbx_set_error("dgrad+wgrad1: null argument"); return DBX_ERR_ARG; }
+    if (d->dtype == DBX_F32) { dbx_set_error("dgrad+wgrad1: 16-bit types only"); return DBX_ERR_DTYPE; }
+    DBX_DISPATCH_DTYPE(d->dtype, conv_dgrad_wgrad1_t, d, dz, w_packed, gate, x0, ci, dw_oihw, db, scratch, accumulate, (hipStream_t)stream);
 }
 
 template <typename T>

@@ -1013,6 +1013,16 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     return DBX_OK;
 }
 
+// the split reduction as a host helper for other translation units (conv_igemm.hip: fused dgrad + conv1_1 weight gradient)
+int dbx_internal_wgrad_reduce(const float* partial, const float* bpartial, int splits, int co, int ci, int taps, int co_pad, int ci_pad,
+                              float* dw, float* db, int accumulate, hipStream_t s) {
+    const long long total = (long long)co * taps * (ci_pad / 4) + (co + 3) / 4;
+    int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, bpartial, splits, co, ci, taps, co_pad, ci_pad, dw, db, accumulate);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
 extern "C" int dbx_conv_wgrad(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, int32_t cpad,
                               int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch, int32_t accumulate, void* stream) {
     if (!dz || !x || !dw_oihw || !scratch) { dbx_set_error("wgrad: null argument"); return DBX_ERR_ARG; }

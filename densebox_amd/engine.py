@@ -805,7 +805,34 @@ class Engine:
             ('conv1_2_1', 'd_a12', 'a11', 64, 64, 'd_a11', 'a11'),
             ('conv1_1_1', 'd_a11', 'x0', 3, 64, None, None),
         ]
+        fused11 = False
         for item in chain:
+            if item[0] == 'conv1_1_1' and fused11:
+                continue                                # its weight gradient came out of conv1_2's data-gradient kernel
+            if item[0] == 'conv1_2_1':
+                # conv1_2's data gradient feeds conv1_1's weight gradient and nothing else: one kernel, no 472 MB map in between
+                stem, dzn, xn, cin, cout, dxn, gaten = item
+                d12 = ConvDesc(dt, 3, 3, 1, 64, 64, _lib.EPI_GATE, 0)
+                dzv, gv, x0v = B[dzn].view(), B[gaten].view(), B['x0'].view()
+                if side is None and os.environ.get('DBX_FUSE_WG1', '1') != '0' and L.dbx_conv_dgrad_wgrad1_fusable(C.byref(d12), C.byref(dzv), C.byref(gv), C.byref(x0v)):
+                    conv_bwd(stem, dzv, B[xn].view(), 3, 3, 1, cout, cin)
+                    need = L.dbx_conv_dgrad_wgrad1_scratch_bytes()
+                    if getattr(self, '_wg1_scratch', None) is None or self._wg1_scratch.numel() < need:
+                        self._wg1_scratch = torch.empty(int(need), dtype=torch.uint8, device=dev)
+                    dw1, db1 = new_grad('conv1_1_1.weight'), new_grad('conv1_1_1.bias')
+                    if prof is not None:
+                        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ev0.record()
+                    check(L.dbx_conv_dgrad_wgrad1(C.byref(d12), C.byref(dzv), ptr(self._w_bwd(dt, stem, 64, 64, frag=False)),
+                                                  C.byref(gv), C.byref(x0v), 3, ptr(dw1), ptr(db1), ptr(self._wg1_scratch), 0, s))
+                    if prof is not None:
+                        ev1.record()
+                        prof.append({'kernel': self.conv_plan(dt, dzv, B[dxn].view(), 3, 3, 1, 64, 64, _lib.EPI_GATE)[1],
+                                     'flops': 2.0 * dzv.n * dzv.h * dzv.w * 9 * 64 * (64 + 3), 'start': ev0, 'end': ev1})
+                    if sink is not None:
+                        sink.ready(['conv1_1_1.weight', 'conv1_1_1.bias'])
+                    fused11 = True
+                    continue
             if item[0] == 'pool':
                 _, xname, dyname, dxname, acc = item
                 xv = c34 if xname == 'fusion' else B[xname].view()

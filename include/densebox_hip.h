@@ -171,6 +171,18 @@ int dbx_conv_wgrad(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t
 int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, char* name, int32_t name_len,
                         int32_t* splits);
 
+/* conv1_2's data gradient with conv1_1's weight/bias gradient folded into its epilogue (DenseBox.py:185-186 backwards):
+ * d = conv_transpose(dz, w) * (gate > 0) is the dz operand of the first layer's weight gradient and of nothing else, so it is
+ * contracted against the 8-channel framed network input x0 inside the kernel and never written:
+ *   dw[co][c][tap] (+)= sum_px d[px][co] * x0[px + tap][c]  (c < ci <= 8),  db[co] (+)= sum_px d[px][co]
+ * -- what dbx_conv_forward(GATE) into a d map followed by dbx_conv_wgrad(d, x0) produce, up to fp32 summation order.
+ * d: the dgrad descriptor (3x3, cpad 1, 64 -> 64, epilogue DBX_EPI_GATE, weights packed with mode 1); exists where
+ * dbx_conv_dgrad_wgrad1_fusable() returns 1.  scratch: dbx_conv_dgrad_wgrad1_scratch_bytes(). */
+int64_t dbx_conv_dgrad_wgrad1_scratch_bytes(void);
+int dbx_conv_dgrad_wgrad1_fusable(const dbx_conv_desc* d, const dbx_view* dz, const dbx_view* gate, const dbx_view* x0);
+int dbx_conv_dgrad_wgrad1(const dbx_conv_desc* d, const dbx_view* dz, const void* w_packed, const dbx_view* gate, const dbx_view* x0,
+                          int32_t ci, float* dw_oihw, float* db, void* scratch, int32_t accumulate, void* stream);
+
 /* ------------------------------------------------------------------ layout / pooling / resampling
  * nchw_to_framed: network input X (DenseBox.py:185) fp32 NCHW -> framed NHWC compute dtype (channels padded with 0).
  * maxpool2x2:     nn.MaxPool2d(2,2) floor mode (DenseBox.py:187,191,204,465), first-max-wins like ATen.

@@ -463,3 +463,54 @@ def test_conv_forward_pool_equals_conv_then_maxpool(shape, dtn):
     # odd sizes: no fused path (the caller runs conv + maxpool)
     fo, to, ov = framed(torch.zeros(n, 64, h + 1, w), 1, tdt)
     assert L.dbx_conv_pool_fusable(C.byref(d), C.byref(ov), C.byref(ov)) == 0
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(2, 24, 40), (3, 37, 61), (20, 64, 96)])
+def test_conv_dgrad_wgrad1_equals_dgrad_then_wgrad(shape, dtn):
+    """dbx_conv_dgrad_wgrad1 (conv1_2's data gradient with conv1_1's weight gradient folded into the epilogue) against the two
+    separate calls it replaces and against torch: dW1, db1 agree up to fp32 summation order."""
+    n, h, w = shape
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    g = torch.Generator(device='cpu').manual_seed(h + w)
+    dz = torch.randn(n, 64, h, w, generator=g).cuda()
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).cuda()           # conv1_2 weights [co2][ci2 = co1]
+    a11 = torch.randn(n, 64, h, w, generator=g).cuda()                                  # conv1_1 output (ReLU gate)
+    x0 = torch.zeros(n, 8, h, w)
+    x0[:, :3] = torch.randn(n, 3, h, w, generator=g)
+    x0 = x0.cuda()
+    fz, tz, zv = framed(dz, 1, tdt)
+    fg, tg, gv = framed(a11, 1, tdt)
+    fx, tx, xv = framed(x0, 1, tdt)
+    wp = pack(L, dt, w2, 64, 64, mode=1)
+    d = ConvDesc(dt, 3, 3, 1, 64, 64, _lib.EPI_GATE)
+    assert L.dbx_conv_dgrad_wgrad1_fusable(C.byref(d), C.byref(zv), C.byref(gv), C.byref(xv)) == 1
+    # the two calls
+    fd, td, dv = framed(torch.zeros(n, 64, h, w), 1, tdt)
+    check(L.dbx_conv_forward(C.byref(d), C.byref(zv), ptr(wp), None, C.byref(dv), C.byref(gv), None, 0, stream_ptr()))
+    dw_a = torch.empty(64, 3, 3, 3, device='cuda'); db_a = torch.empty(64, device='cuda')
+    sc = torch.empty(L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dv), C.byref(xv), 3, 3), dtype=torch.uint8, device='cuda')
+    check(L.dbx_conv_wgrad(dt, C.byref(dv), C.byref(xv), 3, 3, 1, 64, 3, ptr(dw_a), ptr(db_a), ptr(sc), 0, stream_ptr()))
+    # fused
+    dw_b = torch.full((64, 3, 3, 3), 5.0, device='cuda'); db_b = torch.full((64,), 5.0, device='cuda')
+    sc2 = torch.empty(L.dbx_conv_dgrad_wgrad1_scratch_bytes(), dtype=torch.uint8, device='cuda')
+    check(L.dbx_conv_dgrad_wgrad1(C.byref(d), C.byref(zv), ptr(wp), C.byref(gv), C.byref(xv), 3, ptr(dw_b), ptr(db_b), ptr(sc2), 0, stream_ptr()))
+    torch.cuda.synchronize()
+    scale = dw_a.abs().max().item()
+    assert (dw_a - dw_b).abs().max().item() <= 2e-4 * scale + 1e-4, ((dw_a - dw_b).abs().max().item(), scale)
+    assert torch.allclose(db_a, db_b, rtol=1e-4, atol=1e-3 + 1e-5 * db_a.abs().max().item())
+    # torch: d = conv_transpose(dz, w2) * (a11 > 0), rounded to the 16-bit type like the stored map
+    dref = (F.conv_transpose2d(dz.to(tdt).float(), w2.to(tdt).float(), padding=1) * (a11.to(tdt).float() > 0)).to(tdt).float()
+    w1 = torch.zeros(64, 3, 3, 3, device='cuda', requires_grad=True); b1 = torch.zeros(64, device='cuda', requires_grad=True)
+    F.conv2d(x0[:, :3].to(tdt).float(), w1, b1, padding=1).backward(dref)
+    tol = 2e-2 if dtn == 'bf16' else 3e-3
+    assert (dw_b - w1.grad).abs().max().item() <= tol * scale
+    # accumulate, and repeatability bit for bit
+    dw_c = dw_b.clone(); db_c = db_b.clone()
+    check(L.dbx_conv_dgrad_wgrad1(C.byref(d), C.byref(zv), ptr(wp), C.byref(gv), C.byref(xv), 3, ptr(dw_c), ptr(db_c), ptr(sc2), 1, stream_ptr()))
+    dw_d = torch.empty_like(dw_b); db_d = torch.empty_like(db_b)
+    check(L.dbx_conv_dgrad_wgrad1(C.byref(d), C.byref(zv), ptr(wp), C.byref(gv), C.byref(xv), 3, ptr(dw_d), ptr(db_d), ptr(sc2), 0, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(dw_d, dw_b) and torch.equal(db_d, db_b)
+    assert (dw_c - 2 * dw_b).abs().max().item() <= 1e-5 * scale + 1e-6
