@@ -78,12 +78,17 @@ __device__ __forceinline__ size_t geo_pix(const FrameGeo& g, int n, int y, int x
     return ((size_t)(n * g.hp + y + g.pad) * g.wp + (x + g.pad)) * (size_t)g.ld;
 }
 
-// Counter-based dropout keep bits (p = 0.5): bit j of the result is the keep bit of channel 4*c4 + j of pixel m.
-// lowbias32 finaliser over (seed, pixel, channel group): stateless, so forward and backward regenerate identical masks.
-__device__ __forceinline__ unsigned dbx_drop_bits4(unsigned seed, unsigned m, unsigned c4) {
-    unsigned x = seed ^ (m * 0x9E3779B1u) ^ (c4 * 0x85EBCA77u);
+// Counter-based dropout keep bits (p = 0.5).  One lowbias32 finaliser over (seed, pixel m, 32-channel block c32) yields the keep
+// bits of that block's 32 channels (bit j <-> channel 32 c32 + j): stateless, so forward and backward regenerate identical masks,
+// and an epilogue that owns 8+ channels of a pixel pays one hash for all of them.
+__device__ __forceinline__ unsigned dbx_drop_hash32(unsigned seed, unsigned m, unsigned c32) {
+    unsigned x = seed ^ (m * 0x9E3779B1u) ^ (c32 * 0x85EBCA77u);
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
+}
+// bit j of the result is the keep bit of channel 4*c4 + j of pixel m
+__device__ __forceinline__ unsigned dbx_drop_bits4(unsigned seed, unsigned m, unsigned c4) {
+    return (dbx_drop_hash32(seed, m, c4 >> 3) >> ((c4 & 7u) * 4u)) & 15u;
 }
 
 // Fragment-order weight image (conv3x3_ws.hpp; dbx_pack_weight modes 4/5).  One 1-KiB block = the A operand of one v_mfma_f32_32x32x16:

@@ -87,7 +87,9 @@ struct WsArgs {
     int dbg;             // DBX_WS_DBG (development): 1 no periods, 2 no stores, 4 no band DMA, 8 no weight loads
 };
 
-template <typename T, int WM, int KS>
+// EPIK: 0 = the epilogue reads its kind from the arguments at run time; 1 = fixed to BIAS + hash dropout on a single destination
+// (the heads' forward GEMM): the flag tests fold away and with them the ReLU / gate / second-destination code.
+template <typename T, int WM, int KS, int EPIK = 0>
 __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const WsArgs t) {
     using namespace ws;
     constexpr int ES = sizeof(T);
@@ -310,8 +312,8 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
             // (0,1) and (2,3) are exchanged between the lane halves (v_permlane32_swap): every lane stores 16 bytes = eight
             // consecutive couts; the four stores of a pixel fragment complete one 128-byte line per pixel.
             // split destination (1x1 only: the data gradient of the fusion concat): cout tiles at or past split_c go to y2 / gate2
-            const bool second = a.split_c > 0 && cur.n0 >= a.split_c;
-            const int epi = second ? a.epi2 : a.epi;
+            const bool second = EPIK == 0 && a.split_c > 0 && cur.n0 >= a.split_c;
+            const int epi = EPIK == 1 ? (DBX_EPI_BIAS | DBX_EPI_DROPHASH) : (second ? a.epi2 : a.epi);
             char* const ybase = second ? a.y2 : a.y;
             const char* const gbase = second ? a.gate2 : a.gate;
             const int y_hp = second ? a.y2_hp : a.y_hp, y_wp = second ? a.y2_wp : a.y_wp, y_ld = second ? a.y2_ld : a.y_ld, y_pad = second ? a.y2_pad : a.y_pad;
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    bias[ni][j] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cw + ni * 32 + 8 * j + 4 * h) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    bias[ni][j] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cw + ni * 32 + 8 * j + 4 * h) * (EPIK == 1 ? 2.f : 1.f) : (f32x4){0.f, 0.f, 0.f, 0.f};
             int qq = cur.q0 + wm * NF * 32 + l31;
             int n = qq / t.hwp;
             const int rem = qq - n * t.hwp;
@@ -346,6 +348,8 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                 const unsigned mpix = (unsigned)((n * H + oy) * Wo + ox);   // output pixel index (dropout counter)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
+                    unsigned h32 = 0;                                    // EPIK 1: one hash for this wave's 32 couts of the pixel
+                    if constexpr (EPIK == 1) h32 = dbx_drop_hash32(a.drop_seed, mpix, (unsigned)(cw + ni * 32) >> 5);
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
                         u32x2 pk[2];
@@ -353,6 +357,26 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                         for (int jj = 0; jj < 2; ++jj) {
                             const int j = 2 * jp + jj;
                             float v[4];
+                            if constexpr (EPIK == 1) {
+                                // 2 (acc + bias) as two v_pk_fma_f32 (bias pre-doubled); a dropped element is cleared by ANDing
+                                // with the sign-extended one-bit field of the hash (v_bfe_i32 + v_and_b32)
+                                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                                const f32x2 two = {2.f, 2.f};
+                                const f32x2 lo = (f32x2){acc[ni][mi][4 * j], acc[ni][mi][4 * j + 1]} * two + (f32x2){bias[ni][j][0], bias[ni][j][1]};
+                                const f32x2 hi = (f32x2){acc[ni][mi][4 * j + 2], acc[ni][mi][4 * j + 3]} * two + (f32x2){bias[ni][j][2], bias[ni][j][3]};
+                                v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+                                const int kb = (int)(h32 >> (8 * j + 4 * h));      // channels 8 j + 4 h + i of the 32-block
+                                // (inline asm: the compiler rewrites the builtin into v_cmp + v_cndmask, twice the work)
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    int msk;
+                                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(msk) : "v"(kb), "n"(i));
+                                    v[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[i]) & msk);
+                                }
+                                T p1[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
+                                pk[jj] = *(const u32x2*)p1;
+                                continue;
+                            }
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] = acc[ni][mi][4 * j + i] + bias[ni][j][i];
                             if (epi & DBX_EPI_RELU) {
@@ -414,14 +438,14 @@ static inline WsArgs ws_schedule(long long qtot, int hwp, int wm, int ntile_n, i
     return t;
 }
 
-template <typename T, int WM, int KS>
+template <typename T, int WM, int KS, int EPIK = 0>
 static int launch_conv_ws(const ConvArgs& a, int n, int h, int xpad, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
         constexpr int smem = 2 * ws::pieces(WM, KS) * 1024 + ws::D * (256 / WM) * 32;
         static_assert(smem <= 160 * 1024, "LDS budget");
         static bool attr_set = false;
         if (!attr_set) {
-            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<T, WM, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<T, WM, KS, EPIK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
         static int ncu = 0;
@@ -432,7 +456,7 @@ static int launch_conv_ws(const ConvArgs& a, int n, int h, int xpad, hipStream_t
         }
         const WsArgs t = ws_schedule((long long)n * h * a.x_wp, h * a.x_wp, WM, a.ntile_n, ncu, xpad);
         const int grid = t.items < ncu ? t.items : ncu;
-        hipLaunchKernelGGL((conv3x3_ws_kernel<T, WM, KS>), dim3(grid), dim3(256), smem, s, a, t);
+        hipLaunchKernelGGL((conv3x3_ws_kernel<T, WM, KS, EPIK>), dim3(grid), dim3(256), smem, s, a, t);
         DBX_LAUNCH_CHECK();
     }
     return DBX_OK;

@@ -1426,6 +1426,8 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
                              (d->cin_pad >= 256 && (wm == 2 || (!(d->epilogue & DBX_EPI_GATE) && d->cout_pad < 512)));
         if (ws_ok && (wfrag || (plan && (ws_pref || ws_level() >= 2)))) {
             a.ntile_n = ctot / (256 / wm);
+            if (k1 && !y2 && (a.epi & ~DBX_EPI_ACCUM) == (DBX_EPI_BIAS | DBX_EPI_DROPHASH) && ws_level() != 3)      // heads forward: fixed epilogue
+                DBX_SELECT(DBX_K_WS, 256, 256, "conv1x1_ws_kernel", (launch_conv_ws<T, 1, 1, 1>(a, x->n, x->h, x->pad, s)));
             if (k1) DBX_SELECT(DBX_K_WS, 256, 256, "conv1x1_ws_kernel", (launch_conv_ws<T, 1, 1>(a, x->n, x->h, x->pad, s)));
             if (wm == 1) DBX_SELECT(DBX_K_WS, 256, 256, "conv3x3_ws_kernel", (launch_conv_ws<T, 1, 3>(a, x->n, x->h, 1, s)));
             DBX_SELECT(DBX_K_WS, 512, 128, "conv3x3_ws_kernel", (launch_conv_ws<T, 2, 3>(a, x->n, x->h, 1, s)));
