@@ -889,8 +889,10 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     p.bmc = dz->c > 64 ? 128 : 64;
     p.bnc = x->c > 64 ? 128 : 64;
     if (p.bmc != p.bnc) { p.bmc = 64; p.bnc = 64; }        // compiled tile shapes: 128x128 and 64x64
-    // few-channel 3x3 layers: one workgroup accumulates all nine taps of a 64x64 tile
+    // few-channel 3x3 layers (Cout or Cin < 128): one workgroup accumulates all nine taps of a 64x64 tile
     p.alltaps = (dtype != DBX_F32 && kh == 3 && kw == 3 && wgrad_variant() != 1 && ((dz->c <= 128 && x->c <= 128) || wgrad_variant() == 2)) ? 1 : 0;
+    // 128 -> 128 (conv2_2): the row3 kernel measured 10 % faster than the all-taps tile (374 vs 417 us at batch 64; DBX_WGRAD_VARIANT=10: all-taps)
+    if (dz->c == 128 && x->c == 128 && wgrad_variant() != 10 && wgrad_variant() != 2) p.alltaps = 0;
     if (p.alltaps) { p.bmc = 64; p.bnc = 64; }
     // conv1_1: 8-channel (one chunk per pixel) input, 64 couts: (tap, channel) pairs form the GEMM N dimension
     p.c8 = (p.alltaps && x->c * dbx_esize(dtype) == 16 && x->ld == x->c && dz->c == 64 && wgrad_variant() != 4) ? 1 : 0;
