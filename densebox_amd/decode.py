@@ -94,7 +94,7 @@ def detect(net, image, K=10, nms_thresh=0.4):
         import collections
         cache = net.__dict__.setdefault('_detect_graphs', collections.OrderedDict())
         sig = tuple((p._version, p.data_ptr()) for p in net.parameters())
-        key = (tuple(image.shape), image.dtype, K, float(nms_thresh), getattr(net, 'compute_dtype', None))
+        key = (tuple(image.shape), image.dtype, K, float(nms_thresh), net.resolved_dtype(False))
         ent = cache.get(key)
         if ent is None or ent[0] != sig:
             static_in = image.clone()

@@ -436,7 +436,7 @@ class Engine:
             assert X.dim() == 4 and X.size(1) == 3, 'input must be [N,3,H,W]'
             n, _, h, w = X.shape
         L, kind = self.L, self.kind
-        dt = _lib.DTYPE_ID[self.net.compute_dtype]
+        dt = _lib.DTYPE_ID[self.net.resolved_dtype(train)]
         assert h >= 8 and w >= 8, 'input smaller than the /8 stride'
         if kind != 'DenseBox':
             assert h // 8 >= 7 and w // 8 >= 7, 'refine branch (3x3 + 5x5 un-padded convs) needs H/8, W/8 >= 7'

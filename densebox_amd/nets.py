@@ -79,8 +79,17 @@ class _DenseBoxBase(nn.Module):
             for m in (self.conv6_1_det, self.conv6_2_det, self.conv6_3_det):
                 nn.init.xavier_normal_(m.weight.data)
         self._engine = None
-        self.compute_dtype = 'f16'        # 'f16' | 'bf16' | 'f32' -- arithmetic type of the HIP path
+        # arithmetic type of the HIP path: 'f16' | 'bf16' | 'f32', or None = 'bf16' for training steps (fp32's range: the
+        # reference loss is an unscaled sum, a diverging step could overflow f16's 65504 in the gradient maps) and 'f16'
+        # for inference (three more mantissa bits: maps within 2.8e-3 of the reference instead of 2.7e-2)
+        self.compute_dtype = None
         self.dropout_masks = None         # optional injected {head: uint8 [N,512,h,w]} (parity tests)
+
+    def resolved_dtype(self, train=None):
+        if self.compute_dtype is not None:
+            return self.compute_dtype
+        train = self.training if train is None else train
+        return 'bf16' if train else 'f16'
 
     # ------------------------------------------------------------------ engine plumbing
     def engine(self):
