@@ -291,6 +291,15 @@ def main():
                 'launches_per_step': fd['launches'] // 3, 'avg_launch_us': round(fd['us'] / fd['launches'], 2),
                 'families': {k: {'tflops': round(v['flops'] / (v['us'] * 1e-6) / 1e12, 1), 'us_per_step': round(v['us'] / 3, 1),
                                  'launches_per_step': v['launches'] // 3} for k, v in fam.items()}}
+        # north_star's own figure: the whole 3x3 conv stack (every 3x3 layer's forward, data gradient and weight gradient incl.
+        # its split reduction) as algorithmic FLOP over the HIP-event time of those launches, against the same peak
+        def agg(pred):
+            us = sum(v['us'] for k, v in fam.items() if pred(k))
+            fl = sum(v['flops'] for k, v in fam.items() if pred(k))
+            return {'tflops': round(fl / (us * 1e-6) / 1e12, 1), 'frac': round(fl / (us * 1e-6) / 1e12 / peak, 4),
+                    'us_per_step': round(us / 3, 1)} if us > 0 else None
+        roof['stack_3x3'] = {'fwd_dgrad': agg(lambda k: k.startswith('conv3x3_')),
+                             'with_wgrad': agg(lambda k: k.startswith('conv3x3_') or k.startswith('wgrad_row3') or k.startswith('wgrad3x3'))}
         out = {
             'metric': 'training patches/sec (240x240)', 'value': round(value, 1), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
