@@ -249,11 +249,40 @@ __global__ void upsample_kernel(FrameGeo x, FrameGeo y, float sy, float sx) {
         store_vec<T>((T*)y.base + geo_pix(y, n, py, px) + g * V, o);
     }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_rows_kernel(FrameGeo x, FrameGeo y, float sy, float sx) {
+    constexpr int V = Vec<T>::N;
+    const int cg = y.c / V;
+    const int n = blockIdx.x / y.h, py = blockIdx.x - n * y.h;
+    int y0, y1;
+    float ly0, ly1;
+    bilin_coef(py, sy, x.h, y0, y1, ly0, ly1);
+    const T* r0 = (const T*)x.base + geo_pix(x, n, y0, 0);
+    const T* r1 = (const T*)x.base + geo_pix(x, n, y1, 0);
+    T* out = (T*)y.base + geo_pix(y, n, py, 0);
+    const int xs = (int)(geo_pix(x, n, y0, 1) - geo_pix(x, n, y0, 0)), ys = (int)(geo_pix(y, n, py, 1) - geo_pix(y, n, py, 0));
+    const int total = y.w * cg;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int px = e / cg, g = e - px * cg;
+        int x0, x1;
+        float lx0, lx1;
+        bilin_coef(px, sx, x.w, x0, x1, lx0, lx1);
+        float a[V], b[V], c[V], d[V], o[V];
+        load_vec<T>(r0 + (size_t)x0 * xs + g * V, a);
+        load_vec<T>(r0 + (size_t)x1 * xs + g * V, b);
+        load_vec<T>(r1 + (size_t)x0 * xs + g * V, c);
+        load_vec<T>(r1 + (size_t)x1 * xs + g * V, d);
+#pragma unroll
+        for (int j = 0; j < V; ++j) o[j] = ly0 * (lx0 * a[j] + lx1 * b[j]) + ly1 * (lx0 * c[j] + lx1 * d[j]);
+        store_vec<T>(out + (size_t)px * ys + g * V, o);
+    }
+}
 template <typename T> static int upsample_t(const dbx_view* x, const dbx_view* y, hipStream_t s) {
     VIEW_VEC_CHECK(T, x, "upsample x"); VIEW_VEC_CHECK(T, y, "upsample y");
     DBX_REQUIRE(x->c == y->c && x->n == y->n, "upsample: channel/batch mismatch");
-    const int64_t total = (int64_t)y->n * y->h * y->w * (y->c / Vec<T>::N);
-    hipLaunchKernelGGL(upsample_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, make_geo<T>(x), make_geo<T>(y),
+    // one workgroup per output row: the row's two source rows and weights are uniform, a thread walks (pixel, 16-byte channel
+    // group) pairs with 32-bit index math (the flat-index kernel spent its time in 64-bit divisions: 2.3 TB/s -> write-bound)
+    hipLaunchKernelGGL(upsample_rows_kernel<T>, dim3(y->n * y->h), dim3(256), 0, s, make_geo<T>(x), make_geo<T>(y),
                        ac_scale(x->h, y->h), ac_scale(x->w, y->w));
     DBX_LAUNCH_CHECK();
     return DBX_OK;
@@ -309,6 +338,83 @@ __global__ void upsample_bwd_kernel(FrameGeo dy, FrameGeo dx, FrameGeo gate, int
         store_vec<T>((T*)dx.base + geo_pix(dx, n, iy, ix) + g * V, acc);
     }
 }
+// One workgroup per source row: the destination rows that interpolate from it and their weights are found once (same
+// bilin_coef arithmetic as the forward), and so is, per source column, the window of <= 8 destination columns with its weights
+// (LDS table).  A thread then only loads and accumulates, in the same (oy, ox) ascending order as the flat kernel above.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(FrameGeo dy, FrameGeo dx, FrameGeo gate, int has_gate, float sy, float sx) {
+    constexpr int V = Vec<T>::N, WIN = 8, MAXR = 16;
+    extern __shared__ __attribute__((aligned(16))) char up_smem[];
+    int* s_ox0 = (int*)up_smem;                         // [dx.w]
+    float* s_wx = (float*)(s_ox0 + dx.w);               // [dx.w][WIN]
+    __shared__ int s_oy[MAXR];
+    __shared__ float s_wy[MAXR];
+    __shared__ int s_ny;
+    const int cg = dx.c / V;
+    const int n = blockIdx.x / dx.h, iy = blockIdx.x - n * dx.h;
+    if (threadIdx.x == 0) {
+        int lo = sy > 0.f ? (int)floorf((float)(iy - 1) / sy) : 0, hi = sy > 0.f ? (int)ceilf((float)(iy + 1) / sy) : dy.h - 1;
+        lo = max(lo, 0); hi = min(hi, dy.h - 1);
+        int cnt = 0;
+        for (int oy = lo; oy <= hi && cnt < MAXR; ++oy) {
+            int y0, y1; float ly0, ly1;
+            bilin_coef(oy, sy, dx.h, y0, y1, ly0, ly1);
+            const float wy = (y0 == iy ? ly0 : 0.f) + (y1 == iy ? ly1 : 0.f);
+            if (wy != 0.f) { s_oy[cnt] = oy; s_wy[cnt] = wy; ++cnt; }
+        }
+        s_ny = cnt;
+    }
+    for (int ix = threadIdx.x; ix < dx.w; ix += 256) {
+        int lo = sx > 0.f ? (int)floorf((float)(ix - 1) / sx) : 0, hi = sx > 0.f ? (int)ceilf((float)(ix + 1) / sx) : dy.w - 1;
+        lo = max(lo, 0); hi = min(hi, dy.w - 1);
+        int first = -1;
+        float w[WIN];
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) w[k] = 0.f;
+        for (int ox = lo; ox <= hi; ++ox) {
+            int x0, x1; float lx0, lx1;
+            bilin_coef(ox, sx, dx.w, x0, x1, lx0, lx1);
+            const float wx = (x0 == ix ? lx0 : 0.f) + (x1 == ix ? lx1 : 0.f);
+            if (wx != 0.f) {
+                if (first < 0) first = ox;
+                if (ox - first < WIN) w[ox - first] = wx;
+            }
+        }
+        s_ox0[ix] = first < 0 ? 0 : first;
+#pragma unroll
+        for (int k = 0; k < WIN; ++k) s_wx[ix * WIN + k] = w[k];
+    }
+    __syncthreads();
+    const int ny = s_ny, total = dx.w * cg;
+    const int dys = (int)(geo_pix(dy, n, 0, 1) - geo_pix(dy, n, 0, 0));
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int ix = e / cg, g = e - ix * cg;
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc[j] = 0.f;
+        const int ox0 = s_ox0[ix];
+        for (int r = 0; r < ny; ++r) {
+            const float wy = s_wy[r];
+            const T* row = (const T*)dy.base + geo_pix(dy, n, s_oy[r], 0) + g * V;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {
+                const float wx = s_wx[ix * WIN + k];
+                if (wx == 0.f) continue;
+                float d[V];
+                load_vec<T>(row + (size_t)(ox0 + k) * dys, d);
+#pragma unroll
+                for (int j = 0; j < V; ++j) acc[j] += wy * wx * d[j];
+            }
+        }
+        if (has_gate) {
+            float gt[V];
+            load_vec<T>((const T*)gate.base + geo_pix(gate, n, iy, ix) + g * V, gt);
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc[j] = gt[j] > 0.f ? acc[j] : 0.f;
+        }
+        store_vec<T>((T*)dx.base + geo_pix(dx, n, iy, ix) + g * V, acc);
+    }
+}
 template <typename T>
 static int upsample_bwd_t(const dbx_view* dy, const dbx_view* dx, const dbx_view* gate, hipStream_t s) {
     VIEW_VEC_CHECK(T, dy, "upsample_bwd dy"); VIEW_VEC_CHECK(T, dx, "upsample_bwd dx");
@@ -316,8 +422,15 @@ static int upsample_bwd_t(const dbx_view* dy, const dbx_view* dx, const dbx_view
     if (gate) { VIEW_VEC_CHECK(T, gate, "upsample_bwd gate"); DBX_REQUIRE(gate->h == dx->h && gate->w == dx->w && gate->c == dx->c, "upsample_bwd: gate shape"); }
     const int64_t total = (int64_t)dx->n * dx->h * dx->w * (dx->c / Vec<T>::N);
     FrameGeo gg = gate ? make_geo<T>(gate) : make_geo<T>(dx);
-    hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, make_geo<T>(dy), make_geo<T>(dx), gg,
-                       gate ? 1 : 0, ac_scale(dx->h, dy->h), ac_scale(dx->w, dy->w));
+    const float sy = ac_scale(dx->h, dy->h), sx = ac_scale(dx->w, dy->w);
+    // the tabulated kernel covers up-sampling factors up to ~3 (<= 8 destination columns and <= 16 rows per source pixel)
+    const bool rows_ok = sy > 0.34f && sx > 0.34f && dx->w <= 2048;
+    if (rows_ok)
+        hipLaunchKernelGGL(upsample_bwd_rows_kernel<T>, dim3(dx->n * dx->h), dim3(256), (size_t)dx->w * (4 + 8 * 4), s, make_geo<T>(dy), make_geo<T>(dx), gg,
+                           gate ? 1 : 0, sy, sx);
+    else
+        hipLaunchKernelGGL(upsample_bwd_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, make_geo<T>(dy), make_geo<T>(dx), gg,
+                           gate ? 1 : 0, sy, sx);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }

@@ -514,3 +514,36 @@ def test_conv_dgrad_wgrad1_equals_dgrad_then_wgrad(shape, dtn):
     torch.cuda.synchronize()
     assert torch.equal(dw_d, dw_b) and torch.equal(db_d, db_b)
     assert (dw_c - 2 * dw_b).abs().max().item() <= 1e-5 * scale + 1e-6
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16', 'f32'])
+@pytest.mark.parametrize('shape', [(3, 64, 15, 15, 30, 30), (2, 40, 12, 16, 25, 33), (2, 512, 30, 30, 60, 60), (1, 8, 7, 9, 7, 9)])
+def test_upsample_bilinear_forward_backward(shape, dtn):
+    """dbx_upsample_bilinear(_bwd) == F.interpolate(mode='bilinear', align_corners=True) and its autograd transpose (with the
+    optional ReLU gate), on the 2x case, the odd-size case of a 100x132 input and the identity."""
+    n, c, hi, wi, ho, wo = shape
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    g = torch.Generator(device='cpu').manual_seed(sum(shape))
+    x = torch.randn(n, c, hi, wi, generator=g).cuda()
+    fx, tx, xv = framed(x, 1, tdt)
+    fy, ty, yv = framed(torch.zeros(n, c, ho, wo), 1, tdt)
+    check(L.dbx_upsample_bilinear(dt, C.byref(xv), C.byref(yv), stream_ptr()))
+    xr = x.to(tdt).float().requires_grad_(True)
+    ref = F.interpolate(xr, size=(ho, wo), mode='bilinear', align_corners=True)
+    got = ty[:, 1:1 + ho, 1:1 + wo].permute(0, 3, 1, 2).float()
+    tol = {'bf16': 1e-2, 'f16': 2e-3, 'f32': 1e-5}[dtn]
+    assert torch.allclose(got, ref.detach(), rtol=tol, atol=tol), (got - ref).abs().max().item()
+    assert float(ty[:, 0].float().abs().sum()) == 0 and float(ty[:, :, 0].float().abs().sum()) == 0
+    dy = torch.randn(n, c, ho, wo, generator=g).cuda()
+    gate = torch.randn(n, c, hi, wi, generator=g).cuda()
+    fdy, tdy, dyv = framed(dy, 1, tdt)
+    fg, tg, gv = framed(gate, 1, tdt)
+    for use_gate in (False, True):
+        fdx, tdx, dxv = framed(torch.zeros(n, c, hi, wi), 1, tdt)
+        check(L.dbx_upsample_bilinear_bwd(dt, C.byref(dyv), C.byref(dxv), C.byref(gv) if use_gate else None, stream_ptr()))
+        (gref,) = torch.autograd.grad(ref, xr, dy.to(tdt).float(), retain_graph=True)
+        if use_gate:
+            gref = gref * (gate.to(tdt).float() > 0)
+        gotd = tdx[:, 1:1 + hi, 1:1 + wi].permute(0, 3, 1, 2).float()
+        assert torch.allclose(gotd, gref, rtol=tol, atol=tol * (1 + gref.abs().max().item())), (gotd - gref).abs().max().item()
