@@ -847,18 +847,17 @@ struct PackJob { const float* src; void* dst; int co, ci, taps, mode; long long 
 template <typename T>
 __global__ void pack_multi_kernel(const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
-    const long long total = (long long)j.co * j.ci * j.taps;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int total = j.co * j.ci * j.taps, taps = j.taps, ci = j.ci;           // (a layer has < 2^31 weights: 32-bit index math)
+    T* wp = (T*)j.dst;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const float v = j.src[i];
         if (j.mode == 2) { ((float*)j.dst)[j.row_off + i] = v; continue; }        // bias: plain copy into the padded vector
-        const int t = (int)(i % j.taps);
-        const int c = (int)((i / j.taps) % j.ci);
-        const int o = (int)(i / ((long long)j.taps * j.ci));
-        T* wp = (T*)j.dst;
+        const int q = i / taps, t = i - q * taps;
+        const int o = q / ci, c = q - o * ci;
         if (j.mode == 0) wp[(long long)(j.row_off + o) * j.ktot + (long long)t * j.cin_pad + j.k_off + c] = from_f32<T>(v);
-        else if (j.mode == 1) wp[(long long)(j.row_off + c) * j.ktot + (long long)(j.taps - 1 - t) * j.cin_pad + j.k_off + o] = from_f32<T>(v);
-        else if (j.mode == 4) wp[dbx_frag_index(j.row_off + o, t, j.k_off + c, j.cin_pad, (int)j.ktot, j.taps)] = from_f32<T>(v);
-        else wp[dbx_frag_index(j.row_off + c, j.taps - 1 - t, j.k_off + o, j.cin_pad, (int)j.ktot, j.taps)] = from_f32<T>(v);
+        else if (j.mode == 1) wp[(long long)(j.row_off + c) * j.ktot + (long long)(taps - 1 - t) * j.cin_pad + j.k_off + o] = from_f32<T>(v);
+        else if (j.mode == 4) wp[dbx_frag_index(j.row_off + o, t, j.k_off + c, j.cin_pad, (int)j.ktot, taps)] = from_f32<T>(v);
+        else wp[dbx_frag_index(j.row_off + c, taps - 1 - t, j.k_off + o, j.cin_pad, (int)j.ktot, taps)] = from_f32<T>(v);
     }
 }
 template <typename T> static int pack_multi_t(const void* jobs, int count, long long max_elems, hipStream_t s) {
