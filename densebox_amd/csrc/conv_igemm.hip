@@ -1463,6 +1463,12 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             DBX_SELECT(DBX_K_C64, 256, 64, "conv3x3_c64_kernel", (launch_conv_c64<T>(a, x->n, x->h, x->w, s)));
         a.ntile_n = y->c / 64;
         if (tall) { a.nblocks = tiles512 * a.ntile_n; DBX_SELECT(DBX_K_BAND, 512, 64, "conv3x3_band_kernel", (launch_conv_band<T, 512, 64, 3, 8, 1>(a, s))); }
+        // single-image maps (64x64, 128x128): 256-pixel tiles give 0.6 or 1.05 rounds of workgroups on 256 CUs; 128-pixel tiles
+        // (three stages = 63 KB: two workgroups per CU) put more than one workgroup on every CU instead (DBX_CONV_VARIANT=8: off)
+        if ((long long)tiles256 * a.ntile_n <= 320 && conv_variant() != 8) {
+            a.nblocks = (int)((Q + 127) / 128) * a.ntile_n;
+            DBX_SELECT(DBX_K_BAND, 128, 64, "conv3x3_band_kernel", (launch_conv_band<T, 128, 64, 3, 8, 1>(a, s)));
+        }
         a.nblocks = tiles256 * a.ntile_n;
         DBX_SELECT(DBX_K_BAND, 256, 64, "conv3x3_band_kernel", (launch_conv_band<T, 256, 64, 4, 8, 1>(a, s)));
     }
