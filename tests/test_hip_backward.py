@@ -205,3 +205,45 @@ def test_hash_dropout_equals_injected_mask(golden):
     for k, p in net.named_parameters():
         if p.grad is not None:
             assert torch.equal(p.grad, g_hash[k]), k
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+def test_fused_first_layer_gradient_equals_two_kernel_path(golden, dtype, monkeypatch):
+    """The 16-bit training step folds conv1_1's weight gradient into conv1_2's data-gradient kernel (dbx_conv_dgrad_wgrad1) and
+    pool1 into conv1_2's forward.  With DBX_FUSE_WG1=0 the step runs the separate data-gradient and weight-gradient kernels:
+    every other gradient must be bitwise identical, conv1_1's equal up to the fp32 summation order of its 3.7 M-pixel sum."""
+    g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', dtype)
+
+    def grads(fuse):
+        monkeypatch.setenv('DBX_FUSE_WG1', fuse)
+        for p in net.parameters():
+            p.grad = None
+        _, loss = _step(g, kind, net, n, x, 0)
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    la, ga = grads('1')
+    lb, gb = grads('0')
+    assert la == lb
+    for k in ga:
+        if k.startswith('conv1_1_1'):
+            rel = float((ga[k].double() - gb[k].double()).norm() / (gb[k].double().norm() + 1e-30))
+            assert rel <= 2e-5, (k, rel)
+        else:
+            assert torch.equal(ga[k], gb[k]), k
+
+
+def test_eval_and_train_forward_agree_through_fused_pool(golden):
+    """Inference skips the full-resolution conv1_2 map (dbx_conv_forward_pool writes the pooled output only), training writes
+    both: the pooled activation that everything downstream reads is the same bit for bit."""
+    g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', 'f16')
+    xs = x[:n].cuda()
+    eng = net.engine()
+    with torch.no_grad():
+        net(xs)
+    p_train = eng.read_activation('p1').clone()
+    assert float(eng.read_activation('a12').abs().sum()) > 0
+    net.eval()
+    with torch.no_grad():
+        net(xs)
+    p_eval = eng.read_activation('p1').clone()
+    assert torch.equal(p_train, p_eval) and float(p_eval.abs().sum()) > 0
