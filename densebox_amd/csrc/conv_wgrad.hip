@@ -31,6 +31,7 @@ struct WgradArgs {
     int tiles_co, tiles_ci;
     int rows_per_split;                 // multiple of 32
     int nsplit;
+    int hp, nstrips, units, units_per_split;   // strip walk (wgrad3x3_strip_kernel): frame height, 32-pixel column strips per row, N * nstrips
 };
 
 // Workgroup -> (tile, split).  All tiles of one split stream the same frame rows of dz / x, so they should share an L2:
@@ -697,6 +698,184 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ 3x3, all taps, column-strip walk
+// wgrad3x3_kernel walks the frame linearly: the x row it stages as band ky = 2 is needed again as ky = 1 one frame row (7.6
+// steps at 240x240) later and as ky = 0 after another -- by then 512 workgroups have streamed 66 MB through the 32 MB of L2, so
+// every x row is fetched three times from HBM / MALL (conv1_2: 1.9 GB for 0.96 GB of operands; the kernel ran at the same
+// speed with ONE workgroup per CU: bandwidth-bound, not occupancy-bound).  Here a workgroup walks DOWN a 32-pixel column
+// strip of one image: step y needs x rows y-1, y, y+1 of the strip (34 pixels with the kx halo), two of which the previous step
+// already staged -- a four-slot ring of x rows in LDS, ONE new row (4.3 KB) and one dz row (4 KB) per step instead of 17 KB.
+// dz pixels of the last strip that lie past the frame width are zeroed (they alias the next frame row).  Same tile (64 x 64,
+// all nine taps), fragment reads, MFMA schedule, slab layout and bias sums as wgrad3x3_kernel; the K range of a workgroup is
+// units_per_split consecutive (image, strip) units.
+template <int N> struct IC2 { static constexpr int value = N; };
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit tiles");
+    constexpr int R = 32, BAND = R + 2, BROWS = BAND + 2, SLOTS = 4;
+    constexpr int A_BYTES = R * 128, B_BYTES = SLOTS * BROWS * 128;   // 64 channels x 2 B per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // 2 x A_BYTES + B_BYTES = 26 KB
+    char* As = smem;
+    char* Bs = smem + 2 * A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                           // wave tile 32(co) x 32(ci)
+    int t, split;
+    wg_tile_split(a.tiles_co * a.tiles_ci, a.nsplit, t, split);
+    const int tile_ci = t % a.tiles_ci, tile_co = t / a.tiles_ci;
+    const int u0 = split * a.units_per_split, u1 = min(u0 + a.units_per_split, a.units);
+    const bool do_bias = (tile_ci == 0 && a.bpartial != nullptr);
+
+    // ---- loaders: dz 32 pixels x 8 chunks (one per thread); x one row of 34 pixels x 8 chunks (threads 0..255 + 0..15)
+    const int ca = tid & 7, ra = tid >> 3;
+    const bool a_ch_ok = (tile_co * 128 + ca * 16) < a.dz_c * 2;
+    const bool b_ch_ok = (tile_ci * 128 + ca * 16) < a.x_c * 2;
+    const long long a_row = (long long)a.dz_ld * 2, b_row = (long long)a.x_ld * 2;
+    const bool has2 = tid < (BAND * 8 - 256);                          // second x chunk: pixels 32, 33
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    u32x4 areg[2], breg[2][2];                                         // two register sets: loads run TWO steps ahead
+
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[t9][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+    auto bias_acc = [&](int set) {
+        const T* e = (const T*)&areg[set];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += to_f32(e[j]);
+    };
+    const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
+    auto trd = [&](const char* p) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
+    };
+
+    for (int u = u0; u < u1; ++u) {
+        const int n = u / a.nstrips, strip = u - n * a.nstrips;
+        const int cx = strip * R;
+        const long long qimg = (long long)n * a.hp * a.wp;
+        const bool a_ok = a_ch_ok && (cx + ra < a.wp);                  // dz pixels past the frame width alias the next row
+        const char* ap = a.dz + ((qimg + cx + ra) * a.dz_ld + tile_co * 64) * 2LL + ca * 16;
+        const char* bp = a.x + ((qimg + cx + a.shift0 + ra) * a.x_ld + tile_ci * 64) * 2LL + ca * 16;   // pixel ra of the 34
+        // frame row fy of dz; x row index xr (may be -1 or hp: the neighbouring image's halo row / the zero guard, as in the linear walk)
+        // Every lane ALWAYS loads (masked lanes read valid neighbouring memory and are zeroed at the LDS store; lanes without a
+        // second x chunk re-read their first): loads inside divergent or uniform branches make the compiler's counter
+        // bookkeeping fall back to s_waitcnt vmcnt(0) in front of the next issue, which serialises the two-step prefetch.
+        const long long b2 = has2 ? 32 * b_row : 0;
+        auto gload_a = [&](int set, int fy) { areg[set] = *(const u32x4*)(ap + (long long)fy * a.wp * a_row); };
+        auto gload_b = [&](int set, int xr) {
+            breg[set][0] = *(const u32x4*)(bp + (long long)xr * a.wp * b_row);
+            breg[set][1] = *(const u32x4*)(bp + (long long)xr * a.wp * b_row + b2);
+        };
+        auto lstore_a = [&](int set, int buf) {
+            if (!a_ok) areg[set] = zero4;
+            *(u32x4*)(As + buf * A_BYTES + swz16<64>(ra, ca * 16)) = areg[set];
+        };
+        auto lstore_b = [&](int set, int xr) {
+            const int sb = ((xr + 4) & 3) * BROWS;
+            *(u32x4*)(Bs + swz16<64>(sb + ra, ca * 16)) = b_ch_ok ? breg[set][0] : zero4;
+            if (has2) *(u32x4*)(Bs + swz16<64>(sb + 32 + ra, ca * 16)) = b_ch_ok ? breg[set][1] : zero4;
+        };
+        // prologue of the unit: x rows shift0 + 0..2 and dz row 0
+        __syncthreads();                                                 // the previous unit's last reads are done
+#pragma unroll 1
+        for (int i = 0; i < 3; ++i) { gload_b(0, a.shift0 + i); lstore_b(0, a.shift0 + i); }
+        gload_a(0, 0); lstore_a(0, 0); if (do_bias) bias_acc(0);
+        const int nsteps = a.hp;
+        { const int r1 = nsteps > 1 ? 1 : 0; gload_a(1, r1); gload_b(1, r1 + 2 + a.shift0); }   // step 1's operands: set 1
+        __syncthreads();
+        // step s: the loads of step s + 2 go to register set s & 1 (free since its contents were stored at the end of step s - 1);
+        // set (s + 1) & 1 -- issued a whole step ago -- is stored at the end of this step.  The ~1.5 us global latency is
+        // covered by two steps instead of one (one step of 36 MFMAs per wave is 0.3 us).
+        auto step = [&](int s, auto SET_) {
+            constexpr int SET = decltype(SET_)::value;
+            const int buf = s & 1;
+            { const int r2 = s + 2 < nsteps ? s + 2 : nsteps - 1; gload_a(SET, r2); gload_b(SET, r2 + 2 + a.shift0); }   // (clamped: no branch)
+            const char* Ab = As + buf * A_BYTES;
+            const int r0 = 8 * g + rsub;
+            u32x4 af[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const int cbyte = (wm * 32 + mi * 16) * 2 + csub;
+                const u32x2 lo = trd(Ab + swz16<64>(r0, cbyte)), hi = trd(Ab + swz16<64>(r0 + 4, cbyte));
+                af[mi] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+            }
+            struct Run { u32x2 c0, c1, c2; };
+            auto rdRun = [&](int v) {
+                const int cbyte = (wn * 32 + (v & 1) * 16) * 2 + csub, rb = ((s + a.shift0 + (v >> 1) + 4) & 3) * BROWS + r0;
+                Run r;
+                r.c0 = trd(Bs + swz16<64>(rb, cbyte)); r.c1 = trd(Bs + swz16<64>(rb + 4, cbyte)); r.c2 = trd(Bs + swz16<64>(rb + 8, cbyte));
+                return r;
+            };
+            Run run[2];
+            run[0] = rdRun(0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+#pragma unroll
+            for (int v = 0; v < 6; ++v) {
+                const int ky = v >> 1, ni = v & 1;
+                const Run c = run[v & 1];
+                if (v < 5) run[(v + 1) & 1] = rdRun(v + 1);
+                u32x4 bf[3];
+                bf[0] = (u32x4){c.c0.x, c.c0.y, c.c1.x, c.c1.y};
+                bf[1] = (u32x4){__builtin_amdgcn_alignbit(c.c0.y, c.c0.x, 16), __builtin_amdgcn_alignbit(c.c1.x, c.c0.y, 16),
+                                __builtin_amdgcn_alignbit(c.c1.y, c.c1.x, 16), __builtin_amdgcn_alignbit(c.c2.x, c.c1.y, 16)};
+                bf[2] = (u32x4){c.c0.y, c.c1.x, c.c1.y, c.c2.x};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        f32x4& cc = acc[ky * 3 + kx][mi][ni];
+                        if constexpr (DType<T>::id == DBX_F16)
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bf[kx]), __builtin_bit_cast(f16x8, af[mi]), cc, 0, 0, 0);
+                        else
+                            cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[kx]), __builtin_bit_cast(bf16x8, af[mi]), cc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    if (v < 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            // the new x row goes to the slot of row s + shift0 - 1 (dead since the previous step's barrier), dz to the other buffer
+            if (s + 1 < nsteps) { lstore_a(SET ^ 1, buf ^ 1); if (do_bias) bias_acc(SET ^ 1); lstore_b(SET ^ 1, s + 3 + a.shift0); }
+            __syncthreads();
+        };
+        for (int s = 0; s < nsteps; s += 2) {
+            step(s, IC2<0>{});
+            if (s + 1 < nsteps) step(s + 1, IC2<1>{});
+        }
+    }
+
+    {
+        float* P = a.partial + (((long long)split * a.co_pad) * 9) * a.ci_pad;
+        const int co_b = tile_co * 64 + wm * 32 + (lane & 15);
+        const int ci_b = tile_ci * 64 + wn * 32 + (lane >> 4) * 4;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    *(f32x4*)(P + ((long long)(co_b + mi * 16) * 9 + t9) * a.ci_pad + ci_b + ni * 16) = acc[t9][mi][ni];
+    }
+    if (do_bias) {
+        __syncthreads();
+        float* red = (float*)smem;                       // [32 rows][64]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[ra * 64 + ca * 8 + j] = bsum[j];
+        __syncthreads();
+        if (tid < 64) {
+            float sum = 0.f;
+            for (int r = 0; r < 32; ++r) sum += red[r * 64 + tid];
+            a.bpartial[(long long)split * a.co_pad + tile_co * 64 + tid] = sum;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3 with Cin <= 8 (conv1_1)
 // dW[co][tap][c] for an 8-channel (one 16-byte chunk per pixel) input: the GEMM's N dimension is (tap, channel) = 72
 // columns -> five 16-column fragments (two taps x 8 channels each) instead of nine taps x a 64-channel tile that is 7/8
@@ -876,7 +1055,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3, wide; long long Q; };
+struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3, wide; long long Q;
+                   int strip, nstrips, units, units_per_split; };
 
 static int wgrad_variant() {          // DBX_WGRAD_VARIANT=1: generic per-tap kernel everywhere (A/B testing)
     static int v = -1;
@@ -923,6 +1103,19 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     sps = (sps + 1) / 2 * 2;                                   // whole 64-row K steps for the R=64 kernel
     p.rows_per_split = (int)(sps * 32);
     p.splits = (int)splits;                                    // trailing splits may be empty: they write zero slabs
+    // all-taps layers on wide frames: column-strip walk (every x row staged once instead of three times; DBX_WGRAD_VARIANT=11: linear walk)
+    p.strip = (p.alltaps && !p.c8 && dz->w + 2 * dz->pad >= 64 && wgrad_variant() != 11) ? 1 : 0;
+    p.nstrips = p.units = p.units_per_split = 0;
+    if (p.strip) {
+        const int wp = dz->w + 2 * dz->pad;
+        p.nstrips = (wp + 31) / 32;
+        p.units = dz->n * p.nstrips;
+        long long want = (1024 + tiles - 1) / tiles;            // ~4 workgroups per CU over all tiles
+        if (want > p.units) want = p.units;
+        if (want < 1) want = 1;
+        p.units_per_split = (int)((p.units + want - 1) / want);
+        p.splits = (p.units + p.units_per_split - 1) / p.units_per_split;
+    }
     return p;
 }
 
@@ -939,6 +1132,7 @@ extern "C" int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_
     const WgradPlan p = wgrad_plan(dtype, dz, x, kh, kw);
     const char* tn = dtype == DBX_F32 ? "f32" : (dtype == DBX_F16 ? "f16" : "bf16");
     if (p.c8) snprintf(name, name_len, "wgrad3x3_c8_kernel<%s>", tn);
+    else if (p.alltaps && p.strip) snprintf(name, name_len, "wgrad3x3_strip_kernel<%s>", tn);
     else if (p.alltaps) snprintf(name, name_len, "wgrad3x3_kernel<%s>", tn);
     else if (p.row3) snprintf(name, name_len, "wgrad_row3_kernel<%s>", tn);
     else if (p.wide) snprintf(name, name_len, "wgrad_wide_kernel<%s>", tn);
@@ -968,6 +1162,7 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.co_pad = p.co_pad; a.ci_pad = p.ci_pad; a.taps = p.taps; a.kw = kw; a.wp = x->w + 2 * x->pad;
     a.shift0 = x->pad - dz->pad - cpad;
     a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci; a.rows_per_split = p.rows_per_split; a.nsplit = p.splits;
+    a.hp = a.nstrips = a.units = a.units_per_split = 0;
     if (p.c8) {
         if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wgrad3x3_c8_kernel<T>), dim3(p.splits), dim3(256), 0, s, a);
     } else if (p.alltaps) {
@@ -975,11 +1170,18 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
             {
                 constexpr int smem = 2 * (32 * 128 + 3 * 36 * 128);
                 static bool attr_set = false;
+                static int pad = 0;                                   // DBX_WGRAD_LDSPAD: extra dynamic LDS (occupancy experiments)
                 if (!attr_set) {
-                    DBX_HIP(hipFuncSetAttribute((const void*)wgrad3x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                    const char* e = getenv("DBX_WGRAD_LDSPAD"); pad = e ? atoi(e) : 0;
+                    DBX_HIP(hipFuncSetAttribute((const void*)wgrad3x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem + pad));
                     attr_set = true;
                 }
-                hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), smem, s, a);
+                if (p.strip) {
+                    constexpr int smem2 = 2 * 32 * 128 + 4 * 36 * 128;
+                    a.hp = dz->h + 2 * dz->pad; a.nstrips = p.nstrips; a.units = p.units; a.units_per_split = p.units_per_split;
+                    hipLaunchKernelGGL((wgrad3x3_strip_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), smem2, s, a);
+                } else
+                hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), smem + pad, s, a);
             }
     } else if (p.row3) {
         if constexpr (sizeof(T) == 2) {

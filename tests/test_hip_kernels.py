@@ -77,6 +77,7 @@ def test_conv_forward_kernel(case, dtn, variant, monkeypatch):
 WG_CASES = [  # n, h, w, cin (view), cin real, cout, k, pad
     (2, 20, 28, 64, 64, 64, 3, 1), (2, 24, 24, 8, 3, 64, 3, 1), (3, 17, 23, 64, 64, 128, 3, 1), (2, 12, 12, 128, 128, 128, 3, 1),
     (1, 30, 30, 256, 256, 512, 3, 1), (2, 15, 15, 768, 768, 512, 1, 0), (2, 16, 16, 512, 512, 8, 1, 0),
+    (3, 41, 77, 64, 64, 64, 3, 1), (2, 30, 126, 64, 64, 128, 3, 1), (5, 20, 62, 128, 100, 64, 3, 1),      # column-strip walk: ragged last strip
 ]
 
 
