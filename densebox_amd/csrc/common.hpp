@@ -93,14 +93,15 @@ __device__ __forceinline__ unsigned dbx_drop_bits4(unsigned seed, unsigned m, un
 
 // Fragment-order weight image (conv3x3_ws.hpp; dbx_pack_weight modes 4/5).  One 1-KiB block = the A operand of one v_mfma_f32_32x32x16:
 // [lane = 32 * ((k % 16) / 8) + row % 32][k % 8]; blocks ordered [row / BN][period][step][(row % BN) / 32] with
-//   3x3: period = ky * KC + k / 64,  step = kx * 4 + (k % 64) / 16   (tap = 3 ky + kx, KC = cin_pad / 64; 12 steps per period)
+//   3x3: period = 3 * (k / 64) + ky,  step = kx * 4 + (k % 64) / 16   (tap = 3 ky + kx; 12 steps per period; the three ky
+//        bands of one 64-channel chunk are consecutive periods: the second and third re-read rows the first left in L2)
 //   1x1: period = k / 128,           step = (k % 128) / 16           (8 steps per period)
 __host__ __device__ inline size_t dbx_frag_index(int row, int tap, int k, int cin_pad, int rows_pad, int taps) {
     const int bn = rows_pad % 256 == 0 ? 256 : 128;
     int period, step, nstep, nper;
     if (taps == 9) {
         const int KC = cin_pad / 64, ky = tap / 3, kx = tap - 3 * ky;
-        period = ky * KC + k / 64; step = kx * 4 + (k % 64) / 16; nstep = 12; nper = 3 * KC;
+        period = 3 * (k / 64) + ky; step = kx * 4 + (k % 64) / 16; nstep = 12; nper = 3 * KC;
     } else {
         period = k / 128; step = (k % 128) / 16; nstep = 8; nper = cin_pad / 128;
     }

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                 int ab_nxt = 0;
                 if (!last) {
                     if (KS == 3) {
-                        if (++p_kc == KC) { p_kc = 0; ++p_ky; }
+                        if (++p_ky == 3) { p_ky = 0; ++p_kc; }                  // ky fastest: the bands of one chunk share their rows
                         ab_nxt = p_ky * wp * pix_bytes + p_kc * 128;
                     } else {
                         ab_nxt = (m + 1) * 256;

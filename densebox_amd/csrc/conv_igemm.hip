@@ -587,7 +587,9 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
                                                  (__attribute__((address_space(3))) void*)(sbase + (wave + 8 * i) * 1024), 16, 0, 0);
         }
         is_stage = is_stage == STAGES - 1 ? 0 : is_stage + 1;
-        if (++is_kc == kc_steps) { is_kc = 0; ++is_ky; }
+        // ky fastest: the three row bands of one channel chunk are consecutive stages, so the second and third find the rows the
+        // first fetched still in L2 (ky-major order re-fetched every row three times from HBM / MALL: PMC traffic 2x)
+        if (++is_ky == 3) { is_ky = 0; ++is_kc; }
     };
 
     f32x4 acc[NI][MI];

@@ -118,7 +118,7 @@ int dbx_conv_forward_pool(const dbx_conv_desc* d, const dbx_view* x, const void*
  * mode 1: dgrad (transposed) wp[ci][taps-1-tap][co]     = w[co][ci][tap]   (rows = ci, "cin" = co)
  * mode 4 / 5: the same two matrices in MFMA-fragment order for the register-streamed-weights 3x3 kernel (rows_pad a
  *   multiple of 128, cin_pad of 64): element (row, tap = 3 ky + kx, k) at
- *   [row / BN][ky * KC + k / 64][kx * 4 + (k % 64) / 16][(row % BN) / 32][32 * ((k % 16) / 8) + row % 32][k % 8],
+ *   [row / BN][3 * (k / 64) + ky][kx * 4 + (k % 64) / 16][(row % BN) / 32][32 * ((k % 16) / 8) + row % 32][k % 8],
  *   BN = 256 if rows_pad % 256 == 0 else 128, KC = cin_pad / 64 -- one 1-KiB block is the A operand of one
  *   v_mfma_f32_32x32x16 for all 64 lanes.  Same size as modes 0 / 1.
  * ci_off/ci_cnt select an input-channel slice (used to concatenate several heads' 1x1 weights). */

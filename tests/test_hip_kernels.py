@@ -286,7 +286,7 @@ def test_pack_fragment_order_matches_documented_index():
         if ks == 3:
             kc = k // 64
             ky, kx = t_ // 3, t_ % 3
-            blk = ((((r_ // bn) * (3 * kc) + ky * kc + k_ // 64) * 12 + kx * 4 + (k_ % 64) // 16) * (bn // 32) + (r_ % bn) // 32)
+            blk = ((((r_ // bn) * (3 * kc) + 3 * (k_ // 64) + ky) * 12 + kx * 4 + (k_ % 64) // 16) * (bn // 32) + (r_ % bn) // 32)
         else:
             blk = ((((r_ // bn) * (k // 128) + k_ // 128) * 8 + (k_ % 128) // 16) * (bn // 32) + (r_ % bn) // 32)
         idx = (blk * 64 + 32 * ((k_ % 16) // 8) + r_ % 32) * 8 + k_ % 8
@@ -498,9 +498,12 @@ def test_conv_dgrad_wgrad1_equals_dgrad_then_wgrad(shape, dtn):
     sc2 = torch.empty(L.dbx_conv_dgrad_wgrad1_scratch_bytes(), dtype=torch.uint8, device='cuda')
     check(L.dbx_conv_dgrad_wgrad1(C.byref(d), C.byref(zv), ptr(wp), C.byref(gv), C.byref(xv), 3, ptr(dw_b), ptr(db_b), ptr(sc2), 0, stream_ptr()))
     torch.cuda.synchronize()
+    # (the two-call path computes d on whichever conv kernel the plan picks for this size, in its own summation order: single
+    # elements of d may round to the neighbouring 16-bit value, so the sums agree to a few 16-bit ulps of one term, not to fp32)
     scale = dw_a.abs().max().item()
-    assert (dw_a - dw_b).abs().max().item() <= 2e-4 * scale + 1e-4, ((dw_a - dw_b).abs().max().item(), scale)
-    assert torch.allclose(db_a, db_b, rtol=1e-4, atol=1e-3 + 1e-5 * db_a.abs().max().item())
+    rel = 1e-3 if dtn == 'bf16' else 2e-4
+    assert (dw_a - dw_b).abs().max().item() <= rel * scale + 1e-4, ((dw_a - dw_b).abs().max().item(), scale)
+    assert (db_a - db_b).abs().max().item() <= rel * db_a.abs().max().item() + 2e-3, (db_a - db_b).abs().max().item()
     # torch: d = conv_transpose(dz, w2) * (a11 > 0), rounded to the 16-bit type like the stored map
     dref = (F.conv_transpose2d(dz.to(tdt).float(), w2.to(tdt).float(), padding=1) * (a11.to(tdt).float() > 0)).to(tdt).float()
     w1 = torch.zeros(64, 3, 3, 3, device='cuda', requires_grad=True); b1 = torch.zeros(64, device='cuda', requires_grad=True)
