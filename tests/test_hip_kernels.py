@@ -198,13 +198,14 @@ WS_CASES = [(32, 30, 30, 512, 512), (16, 60, 60, 256, 256), (40, 30, 30, 256, 51
 
 
 def _ws_desc(L, dt, xv, yv, cin, cout, epi):
-    """The plan prefers the ws kernel where it measured faster than the band kernel (>= 512 input channels; 256 unless the
-    epilogue gates or there are 512 couts); DBX_CONV_WFRAG forces it on any problem it can run, which is what these tests do."""
+    """The plan prefers the ws kernel where it measured faster than the band kernel (un-gated 512 -> 512 and 256 -> 256 layers,
+    128-cout layers with >= 256 input channels); DBX_CONV_WFRAG forces it on any problem it can run, which is what these tests do."""
     d = ConvDesc(dt, 3, 3, 1, cin, cout, epi)
     plan = _lib.ConvPlan()
     check(L.dbx_conv_plan(C.byref(d), C.byref(xv), C.byref(yv), C.byref(plan)))
     wm = 1 if cout % 256 == 0 else 2
-    pref = cin >= 512 or (cin >= 256 and (wm == 2 or (not (epi & _lib.EPI_GATE) and cout < 512)))
+    nogate = not (epi & _lib.EPI_GATE)
+    pref = (wm == 2 and cin >= 256) or (nogate and wm == 1 and ((cin >= 512 and cout >= 512) or (cin == 256 and cout == 256)))
     assert (plan.kernel == _lib.K_WS and plan.w_frag == 1) == pref, (plan.kernel, plan.name)
     if pref:
         assert plan.name.decode().startswith('conv3x3_ws_kernel<')
