@@ -501,6 +501,30 @@ extern "C" int dbx_framed_add_ch(int32_t dtype, const dbx_view* src, int32_t c_s
 // slice of the fp32 master weights in registers -- so that a pixel's 512*nh channels leave as one contiguous burst.
 struct Head2Args { const float* w2[4]; int k[4]; int nh; int slot; };
 
+// The lane's k x V slice of its head's fp32 weights.  The head's pointer and k are SELECTED from the kernel arguments (constant
+// indices: scalar registers) and the rows fetched with 16-byte loads of a clamped row index -- indexing the argument arrays with
+// the per-lane head number made the compiler read them through memory, one dependent pointer load + one scalar load per
+// element, each behind s_waitcnt vmcnt(0): 128 serialised round trips (~50 us) at the head of every workgroup.
+template <int V>
+__device__ __forceinline__ void head2_load_w(const Head2Args& ha, int hd, int c0, bool active, float (&w)[8][V], int& k_out) {
+    const float* wp = ha.w2[0];
+    int k = ha.k[0];
+#pragma unroll
+    for (int hh = 1; hh < 4; ++hh)
+        if (hd == hh && ha.w2[hh]) { wp = ha.w2[hh]; k = ha.k[hh]; }
+    k_out = k;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = j < k ? j : (k > 0 ? k - 1 : 0);
+        const bool use = active && j < k;
+#pragma unroll
+        for (int q = 0; q < V / 4; ++q) {
+            const f32x4 v = *(const f32x4*)(wp + (size_t)row * 512 + c0 + 4 * q);
+            w[j][4 * q] = use ? v.x : 0.f; w[j][4 * q + 1] = use ? v.y : 0.f; w[j][4 * q + 2] = use ? v.z : 0.f; w[j][4 * q + 3] = use ? v.w : 0.f;
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(512) void head2_dgrad_kernel(FrameGeo dout, Head2Args ha, FrameGeo dhid,
                                                           const unsigned char* __restrict__ mask, int mask_ld, int use_hash,
@@ -512,12 +536,9 @@ __global__ __launch_bounds__(512) void head2_dgrad_kernel(FrameGeo dout, Head2Ar
     const int sub = threadIdx.x % lph_all;        // position inside the pixel
     const int hd = sub / LPH, c0 = (sub % LPH) * V;
     const bool active = threadIdx.x < ppb * lph_all;
-    const int k = ha.k[hd];
+    int k;
     float w[8][V];
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-#pragma unroll
-        for (int i = 0; i < V; ++i) w[j][i] = (active && j < k) ? ha.w2[hd][j * 512 + c0 + i] : 0.f;
+    head2_load_w<V>(ha, hd, c0, active, w, k);
     if (!active) return;
     const int nrows = dhid.n * dhid.h;            // one workgroup per image row: no division in the pixel loop
     for (int row = blockIdx.x; row < nrows; row += gridDim.x) {
@@ -571,7 +592,7 @@ static int head2_dgrad_t(const dbx_view* dout, const float* const* w2, const int
                     ((dout->c / nh) * sizeof(T)) % 16 == 0, "head2_dgrad: d_out alignment");
     Head2Args ha;
     ha.nh = nh; ha.slot = dout->c / nh;
-    for (int i = 0; i < 4; ++i) { ha.w2[i] = i < nh ? w2[i] : nullptr; ha.k[i] = i < nh ? k[i] : 0; if (i < nh) DBX_REQUIRE(k[i] >= 1 && k[i] <= 8 && w2[i], "head2_dgrad: k in 1..8"); }
+    for (int i = 0; i < 4; ++i) { ha.w2[i] = i < nh ? w2[i] : nullptr; ha.k[i] = i < nh ? k[i] : 0; if (i < nh) DBX_REQUIRE(k[i] >= 1 && k[i] <= 8 && w2[i] && ((size_t)w2[i] % 16) == 0, "head2_dgrad: k in 1..8, 16-byte aligned weights"); }
     const int lph_all = (512 / Vec<T>::N) * nh;
     const int threads = lph_all <= 256 ? 256 : 512;
     int blocks = dhid->n * dhid->h; blocks = blocks > 8192 ? 8192 : blocks;
@@ -623,14 +644,8 @@ __global__ __launch_bounds__(512) void head2_wgrad_kernel(FrameGeo dout, FrameGe
     const long long npix = (long long)hid.n * hid.h * hid.w;
     const long long per = (npix + gridDim.x - 1) / gridDim.x;
     const long long p0 = (long long)blockIdx.x * per, p1 = p0 + per < npix ? p0 + per : npix;
-    float w[DG ? 8 : 1][V];
-    if constexpr (DG) {
-        const int k = ha.k[hd];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int i = 0; i < V; ++i) w[j][i] = (active && j < k) ? ha.w2[hd][j * 512 + c0 + i] : 0.f;
-    }
+    float w[8][V];
+    if constexpr (DG) { int k; head2_load_w<V>(ha, hd, c0, active, w, k); }
     if (active && p0 + grp < p1) {
         long long p = p0 + grp;
         int n = (int)(p / ((long long)hid.h * hid.w));
@@ -812,7 +827,7 @@ static int head2_wgrad_t(const dbx_view* dout, const dbx_view* hid, const int32_
     if (dhid) {
         VIEW_VEC_CHECK(T, dhid, "head2_backward d_hid");
         DBX_REQUIRE(w2 && dhid->c == 512 * nh && dout->n == dhid->n && dout->h == dhid->h && dout->w == dhid->w, "head2_backward: d_hid of 512*nh channels on the d_out grid");
-        for (int i = 0; i < nh; ++i) DBX_REQUIRE(w2[i], "head2_backward: null weight");
+        for (int i = 0; i < nh; ++i) DBX_REQUIRE(w2[i] && ((size_t)w2[i] % 16) == 0, "head2_backward: null or unaligned weight");
         hipLaunchKernelGGL((head2_wgrad_kernel<T, true>), dim3(blocks), dim3(threads), 0, s, make_geo<T>(dout), make_geo<T>(hid), nh, dout->c / nh,
                            partial, bpartial, ha, make_geo<T>(dhid), mask, mask_ld, use_hash, drop_seed);
     } else
