@@ -3,6 +3,8 @@
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/band_lab.hip -o tools/band_lab
 // run:   tools/band_lab [variants, e.g. 0,5,6] [reps]
 #include "../densebox_amd/csrc/conv_igemm.hip"
+// conv_igemm.hip calls into conv_wgrad.hip for the fused dgrad + weight-gradient entry point; the lab links one translation unit
+int dbx_internal_wgrad_reduce(const float*, const float*, int, int, int, int, int, int, float*, float*, int, hipStream_t) { return DBX_ERR_ARG; }
 #include <vector>
 #include <string>
 #include <math.h>
