@@ -10,7 +10,7 @@
 
 #define HWD 60
 #define NPIX 3600
-#define LOSS_THREADS 256
+#define LOSS_THREADS 1024
 
 // ---------------------------------------------------------------------------------------------- integer helpers
 __device__ __forceinline__ int norm_idx(int v) {            // python slice index normalisation on a dim of 60
@@ -97,9 +97,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(const LossArgs a) {
     __shared__ float negl[NPIX];
     __shared__ unsigned char mask[NPIX];
     __shared__ unsigned char lmask[4][NPIX];
-    __shared__ float red_v[4];
-    __shared__ int red_i[4];
-    __shared__ double red_d[4];
+    __shared__ float red_v[LOSS_THREADS / 64];
+    __shared__ int red_i[LOSS_THREADS / 64];
+    __shared__ double red_d[LOSS_THREADS / 64];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int kind = a.d.kind, N = a.d.n, K = a.d.half_neg;
     const dbx_loss_io& io = a.io;
