@@ -32,6 +32,7 @@ struct WgradArgs {
     int rows_per_split;                 // multiple of 32
     int nsplit;
     int hp, nstrips, units, units_per_split;   // strip walk (wgrad3x3_strip_kernel): frame height, 32-pixel column strips per row, N * nstrips
+    int spi, img_rows, row0, steps_total, steps_per_split;   // compact walk (wgrad_row3_kernel): 64-row steps per image over its valid rows only
 };
 
 // Workgroup -> (tile, split).  All tiles of one split stream the same frame rows of dz / x, so they should share an L2:
@@ -397,25 +398,40 @@ __global__ __launch_bounds__(512) void wgrad_row3_kernel(const WgradArgs a) {
     const int tile_ci = t % a.tiles_ci; t /= a.tiles_ci;
     const int tile_co = t % a.tiles_co; t /= a.tiles_co;
     const int ky = t;
-    const long long q0 = (long long)split * a.rows_per_split;
+    // K range.  Linear walk: rows [split * rows_per_split, ...) of the whole frame.  Compact walk (a.spi > 0): a step is 64 rows of
+    // ONE image's valid rows (frame rows pad .. pad + H - 1: dz is zero in the halo rows, so they need no MFMAs: 15 instead of
+    // 16 steps per 32 x 32 frame); the last step of an image runs over into its bottom halo row and the next image's top one
+    // (zeros: Wp >= 32).
+    const bool compact = a.spi > 0;
+    const int gs0 = compact ? split * a.steps_per_split : 0;
+    const long long q0 = compact ? 0 : (long long)split * a.rows_per_split;
     long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
-    const int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
+    int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
+    if (compact) { const int gs1 = min(gs0 + a.steps_per_split, a.steps_total); nsteps = gs1 > gs0 ? gs1 - gs0 : 0; }
+    auto qof = [&](int s) -> long long {
+        if (!compact) return q0 + 64LL * s;
+        const int gsx = gs0 + s, img = gsx / a.spi, j = gsx - img * a.spi;
+        return (long long)img * a.img_rows + a.row0 + 64LL * j;
+    };
     const bool do_bias = (tile_ci == 0 && ky == 0 && a.bpartial != nullptr);
 
     // loaders: thread t owns chunk t%16 of dz rows t/16 and t/16+32, of band rows t/16 and t/16+32, and (t < 32) of row t/16+64
     const int ca = tid & 15, ra = tid >> 4;
-    const char* ap = a.dz + ((q0 + ra) * a.dz_ld + tile_co * 128) * 2LL + ca * 16;
-    const long long xrow0 = q0 + (long long)(ky + a.shift0) * a.wp + a.shift0;
-    const char* bp = a.x + ((xrow0 + ra) * a.x_ld + tile_ci * 128) * 2LL + ca * 16;
+    const char* apb = a.dz + ((long long)ra * a.dz_ld + tile_co * 128) * 2LL + ca * 16;
+    const long long xshift = (long long)(ky + a.shift0) * a.wp + a.shift0;
+    const char* bpb = a.x + ((xshift + ra) * a.x_ld + tile_ci * 128) * 2LL + ca * 16;
     const long long a32 = 32LL * a.dz_ld * 2, b32 = 32LL * a.x_ld * 2;
     const bool has2 = tid < 32;
     u32x4 areg[2], breg[3];
     auto gload = [&](int s) {
-        areg[0] = *(const u32x4*)(ap + s * 2 * a32);
-        areg[1] = *(const u32x4*)(ap + s * 2 * a32 + a32);
-        breg[0] = *(const u32x4*)(bp + s * 2 * b32);
-        breg[1] = *(const u32x4*)(bp + s * 2 * b32 + b32);
-        if (has2) breg[2] = *(const u32x4*)(bp + s * 2 * b32 + 2 * b32);
+        const long long qs = qof(s);
+        const char* ap = apb + qs * a.dz_ld * 2LL;
+        const char* bp = bpb + qs * a.x_ld * 2LL;
+        areg[0] = *(const u32x4*)(ap);
+        areg[1] = *(const u32x4*)(ap + a32);
+        breg[0] = *(const u32x4*)(bp);
+        breg[1] = *(const u32x4*)(bp + b32);
+        if (has2) breg[2] = *(const u32x4*)(bp + 2 * b32);
     };
     auto lstore = [&](int buf) {
         *(u32x4*)(As + buf * A_BYTES + swz16<128>(ra, ca * 16)) = areg[0];
@@ -1056,7 +1072,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------ host
 struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3, wide; long long Q;
-                   int strip, nstrips, units, units_per_split; };
+                   int strip, nstrips, units, units_per_split, spi, steps_total, steps_per_split; };
 
 static int wgrad_variant() {          // DBX_WGRAD_VARIANT=1: generic per-tap kernel everywhere (A/B testing)
     static int v = -1;
@@ -1104,6 +1120,13 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     p.rows_per_split = (int)(sps * 32);
     p.splits = (int)splits;                                    // trailing splits may be empty: they write zero slabs
     // all-taps layers on wide frames: column-strip walk (every x row staged once instead of three times; DBX_WGRAD_VARIANT=11: linear walk)
+    // row3: 64-row steps over the valid rows of each image only (DBX_WGRAD_VARIANT=14: linear walk over the whole frame)
+    p.spi = p.steps_total = p.steps_per_split = 0;
+    if (p.row3 && dz->pad == 1 && dz->w + 2 >= 32 && wgrad_variant() != 14) {
+        p.spi = (dz->h * (dz->w + 2) + 63) / 64;
+        p.steps_total = dz->n * p.spi;
+        p.steps_per_split = (p.steps_total + p.splits - 1) / p.splits;
+    }
     p.strip = (p.alltaps && !p.c8 && dz->w + 2 * dz->pad >= 64 && wgrad_variant() != 11) ? 1 : 0;
     p.nstrips = p.units = p.units_per_split = 0;
     if (p.strip) {
@@ -1163,6 +1186,8 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.shift0 = x->pad - dz->pad - cpad;
     a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci; a.rows_per_split = p.rows_per_split; a.nsplit = p.splits;
     a.hp = a.nstrips = a.units = a.units_per_split = 0;
+    a.spi = p.spi; a.img_rows = (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad); a.row0 = (dz->w + 2 * dz->pad) * dz->pad;
+    a.steps_total = p.steps_total; a.steps_per_split = p.steps_per_split;
     if (p.c8) {
         if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wgrad3x3_c8_kernel<T>), dim3(p.splits), dim3(256), 0, s, a);
     } else if (p.alltaps) {
