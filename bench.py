@@ -298,6 +298,14 @@ def main():
             fl = sum(v['flops'] for k, v in fam.items() if pred(k))
             return {'tflops': round(fl / (us * 1e-6) / 1e12, 1), 'frac': round(fl / (us * 1e-6) / 1e12 / peak, 4),
                     'us_per_step': round(us / 3, 1)} if us > 0 else None
+        # the dominant forward / data-gradient conv family on its own (round 1's dominant kernel was one: continuity of the series)
+        convs = {k: v for k, v in fam.items() if k.startswith('conv3x3_') or k.startswith('conv1x1_')}
+        if convs:
+            dc = max(convs, key=lambda k: convs[k]['us'])
+            ac = convs[dc]['flops'] / (convs[dc]['us'] * 1e-6) / 1e12
+            roof['dominant_conv'] = {'kernel': dc, 'achieved': round(ac, 1), 'frac': round(ac / peak, 4),
+                                     'launches_per_step': convs[dc]['launches'] // 3, 'us_per_step': round(convs[dc]['us'] / 3, 1),
+                                     'traffic': pmc_traffic(dc)}
         roof['stack_3x3'] = {'fwd_dgrad': agg(lambda k: k.startswith('conv3x3_')),
                              'with_wgrad': agg(lambda k: k.startswith('conv3x3_') or k.startswith('wgrad_row3') or k.startswith('wgrad3x3'))}
         out = {
