@@ -84,8 +84,16 @@ struct WsArgs {
     int hwp;             // H * Wp: q' per image
     int qtot;            // N * H * Wp
     int xpad;            // frame width of x (1; 0 for an unframed 1x1 input): halo columns fx < xpad, fx >= Wp - xpad are dropped
-    int dbg;             // DBX_WS_DBG (development): 1 no periods, 2 no stores, 4 no band DMA, 8 no weight loads
+#ifdef DBX_LAB
+    int dbg;             // DBX_WS_DBG (lab builds only): 1 no periods, 2 no stores, 4 no band DMA, 8 no weight loads
+#endif
 };
+// ablation bits: a run-time field in lab builds (tools/band_lab.hip), the constant 0 in the product library (the tests fold away)
+#ifdef DBX_LAB
+#define WS_DBG(t) ((t).dbg)
+#else
+#define WS_DBG(t) 0
+#endif
 
 // EPIK: 0 = the epilogue reads its kind from the arguments at run time; 1 = fixed to BIAS + hash dropout on a single destination
 // (the heads' forward GEMM): the flag tests fold away and with them the ReLU / gate / second-destination code.
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
             // ONE period body for every period of the tile (a FIRST / LAST specialisation triples the code and the register
             // pressure: the compiler then spills lane invariants and drains the pipeline around every reload).  What differs is
             // scalar: whose band is prefetched, two skipped waits at the tile start, extra LDS-DMA at the tile end.
-            for (int m = 0; m < ((t.dbg & 1) ? 0 : P); ++m) {
+            for (int m = 0; m < ((WS_DBG(t) & 1) ? 0 : P); ++m) {
                 const bool first = m == 0, last = m == P - 1;
                 if (last && more) nxt = tile_of(nxt_item);
                 int ab_nxt = 0;
@@ -289,8 +297,8 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                         Mma32<T>::run(wr[wsx][k / NF], xf[xs][k % NF], acc[k / NF][k % NF]);
                         // (not in a tile's very last step: its band is the next tile's, still landing -- the tile start reads it)
                         if (k < NF && !(last && j == NSTEP - 1)) xf[xs ^ 1][k] = *(const u32x4*)(xp + k * 4096);
-                        if (k == NF + 1 && !(t.dbg & 8)) wload(wnx);    // (a tile's last D steps run past its stream: drained, unused)
-                        if (k == NF + 3 && GA > 0 && !(t.dbg & 4)) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0);
+                        if (k == NF + 1 && !(WS_DBG(t) & 8)) wload(wnx);    // (a tile's last D steps run past its stream: drained, unused)
+                        if (k == NF + 3 && GA > 0 && !(WS_DBG(t) & 4)) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0);
                         if (k == NF + 5 && GA > 1) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 1);
                         if (k == NF + 6 && GA > 2) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 2);
                         if (k == NM - 1 && GA > 3) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 3);
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                         const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                         const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                         u32x4 o = (u32x4){r0[0], r1[0], r0[1], r1[1]};
-                        if (ok && !(t.dbg & 2)) {
+                        if (ok && !(WS_DBG(t) & 2)) {
                             if (epi & DBX_EPI_GATE) o = gate_packed16(o, gt[ni][jp]);
                             *(u32x4*)(ypix + ni * 32 + 16 * jp) = o;
                         }
@@ -434,7 +442,9 @@ static inline WsArgs ws_schedule(long long qtot, int hwp, int wm, int ntile_n, i
     }
     t.mt = (int)mt; t.base = (int)(units / mt); t.extra = (int)(units % mt);
     t.items = (int)(mt * ntile_n); t.hwp = hwp; t.qtot = (int)qtot; t.xpad = xpad;
+#ifdef DBX_LAB
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DBX_WS_DBG"); dbg = e ? atoi(e) : 0; } t.dbg = dbg; }
+#endif
     return t;
 }
 

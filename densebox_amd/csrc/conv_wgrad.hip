@@ -17,6 +17,7 @@
 #include <stdio.h>
 
 typedef short short4v __attribute__((ext_vector_type(4)));
+template <int N> struct IC2 { static constexpr int value = N; };
 
 struct WgradArgs {
     const char* dz; const char* x;      // pointing at frame origin, channel c_off
@@ -543,6 +544,208 @@ __global__ __launch_bounds__(512) void wgrad_row3_kernel(const WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 wide layers, round 3: all nine taps, LDS-DMA ring
+// wgrad_row3_kernel above splits a (co, ci) tile over three workgroups (one per ky) and 16 K ranges: 768 workgroups write
+// 151 MB of fp32 slabs per launch for <= 9.4 MB of dW, its register-staged double buffer puts five ds_write_b128 and the
+// vmcnt(0) they need between the last MFMA of a step and the barrier, and the first transpose reads of the next step start
+// from an idle pipe.  This kernel:
+//   * tile = 128(co) x 64(ci) x ALL NINE taps: 256 workgroups (one per CU, one round) -- half the slab bytes and half the splits
+//     to reduce, dz fragments read once for nine taps (17 transpose reads per 36 MFMAs instead of 14 per 24);
+//   * operands go global -> LDS by LDS-DMA (no staging registers, no ds_write, no vmcnt(0) in the loop): a stage is the dz
+//     tile (64 rows x 256 B, 16 pieces) + three x bands (ky = 0..2: 72 rows x 128 B each, 27 pieces); the XOR swizzles of
+//     the transpose reads are applied on the DMA source addresses;
+//   * three-stage ring, ONE barrier per 64-row step placed in front of the step's last unit: tile s+2 is issued at the top of
+//     step s (its stage held tile s-1, whose last read precedes the previous barrier), tile s+1 is waited for (counted vmcnt)
+//     in front of the barrier, and the first fragments of tile s+1 are read behind it, under the last 12 MFMAs of step s --
+//     the barrier never waits for data and no step starts with an empty pipe;
+//   * the bias gradient comes from an MFMA against a ones fragment (each wave one of its four co fragments, in the steps
+//     assigned to its ci tile): no extra LDS reads, no VALU reduction.
+// 8 waves as 2(co) x 4(ci), 64 x 16 per wave, 9 x 4 accumulator fragments.  Requires dz_c % 128 == 0, x_c % 64 == 0.
+// Grid: (co-tile, ci-tile) x split-K; bias partial rows = splits * tiles_ci.
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_all9_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit tiles");
+    constexpr int R = 64, BROWS = 72;
+    constexpr int A_BYTES = R * 256, BAND_BYTES = BROWS * 128;
+    constexpr int STAGE = A_BYTES + 3 * BAND_BYTES;                     // 44032 B
+    constexpr int AP = A_BYTES / 1024, BP = 3 * BAND_BYTES / 1024, NPIECE = AP + BP, SLOTS = (NPIECE + 7) / 8;   // 16 + 27 pieces, 6 slots
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // 3 x STAGE = 129 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                           // wave tile 64(co) x 16(ci)
+    int t, split;
+    wg_tile_split(a.tiles_co * a.tiles_ci, a.nsplit, t, split);
+    const int tile_ci = t % a.tiles_ci, tile_co = t / a.tiles_ci;
+    // K range: as wgrad_row3_kernel (compact walk over the valid rows of each image when a.spi > 0)
+    const bool compact = a.spi > 0;
+    const int gs0 = compact ? split * a.steps_per_split : (int)(((long long)split * a.rows_per_split) / R);
+    const long long q0 = compact ? 0 : (long long)split * a.rows_per_split;
+    long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
+    int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
+    if (compact) { const int gs1 = min(gs0 + a.steps_per_split, a.steps_total); nsteps = gs1 > gs0 ? gs1 - gs0 : 0; }
+    auto qof = [&](int s) -> long long {
+        if (!compact) return q0 + 64LL * s;
+        const int gsx = gs0 + s, img = gsx / a.spi, j = gsx - img * a.spi;
+        return (long long)img * a.img_rows + a.row0 + 64LL * j;
+    };
+
+    // ---- LDS-DMA sources.  A piece = 4 dz rows (lane: row l>>4, chunk position l&15), a B piece = 8 band rows (row l>>3, chunk
+    // position l&7); position p of LDS row r receives source chunk p ^ mask(r) (swz16<128> / swz16<64>): the row bits that come
+    // from the lane are folded into the lane offset, the one that comes from the piece index is a uniform XOR.
+    const long long dzrow = (long long)a.dz_ld * 2, xrow = (long long)a.x_ld * 2;
+    const char* dzb = a.dz + tile_co * 256;
+    const char* xb = a.x + tile_ci * 128 + (long long)a.shift0 * (a.wp + 1) * xrow;
+    const unsigned laA = (unsigned)(lane >> 4) * (unsigned)dzrow + (unsigned)(((lane & 15) ^ ((lane >> 4) << 1)) << 4);
+    const unsigned laB = (unsigned)(lane >> 3) * (unsigned)xrow + (unsigned)(((lane & 7) ^ (((lane >> 4) & 1) << 1)) << 4);
+    // The DMA goes out as inline asm (saddr form: uniform base + one lane offset register): for the builtin the compiler's
+    // waitcnt pass puts s_waitcnt vmcnt(0) in front of the next transpose read (it cannot prove that the ds_read_tr intrinsic
+    // does not alias the LDS-DMA destination), which drains the ring every step.  Invisible to that pass, the loads are counted by
+    // hand: the only other VMEM operations of the kernel are the slab stores behind the final vmcnt(0).
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    auto issue = [&](int s, int stage) {
+        const long long qs = qof(s);
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            int pid = wave + 8 * i;
+            if (pid >= NPIECE) pid -= 8;                                // (uniform) every wave issues SLOTS loads: counted waits
+            const char* src;
+            unsigned voff;
+            if (pid < AP) {
+                src = dzb + (qs + 4 * pid) * dzrow;
+                voff = laA ^ (unsigned)(((pid >> 1) & 1) << 7);
+            } else {
+                const int pb = pid - AP, band = pb / 9, pr = pb - band * 9;
+                src = xb + (qs + (long long)band * a.wp + 8 * pr) * xrow;
+                voff = laB ^ (unsigned)((pb & 1) << 6);
+            }
+            const unsigned dst = lds0 + stage * STAGE + pid * 1024;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[tp][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
+    const unsigned one2 = DType<T>::id == DBX_F16 ? 0x3C003C00u : 0x3F803F80u;
+    const u32x4 ones = {one2, one2, one2, one2};
+    const bool do_bias = a.bpartial != nullptr;
+
+    const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
+    auto trd = [&](const char* p) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
+    };
+    auto rdA = [&](const char* Sb, int kk, int mi) {
+        const int r0 = 32 * kk + 8 * g + rsub, cbyte = (wm * 64 + mi * 16) * 2 + csub;
+        const u32x2 lo = trd(Sb + swz16<128>(r0, cbyte)), hi = trd(Sb + swz16<128>(r0 + 4, cbyte));
+        return (u32x4){lo.x, lo.y, hi.x, hi.y};
+    };
+    struct Run { u32x2 r0, r1, r2; };          // band rows r .. r+11 of one channel column (see wgrad_row3_kernel)
+    auto rdRun = [&](const char* Sb, int kk, int ky) {
+        const int r0 = ky * BROWS + 32 * kk + 8 * g + rsub, cbyte = (wn * 16) * 2 + csub;
+        const char* Bb = Sb + A_BYTES;
+        Run r;
+        r.r0 = trd(Bb + swz16<64>(r0, cbyte)); r.r1 = trd(Bb + swz16<64>(r0 + 4, cbyte)); r.r2 = trd(Bb + swz16<64>(r0 + 8, cbyte));
+        return r;
+    };
+    auto mma = [&](const u32x4& xf, const u32x4& zf, f32x4& c) {
+        if constexpr (DType<T>::id == DBX_F16)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf), __builtin_bit_cast(f16x8, zf), c, 0, 0, 0);
+        else
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, zf), c, 0, 0, 0);
+    };
+
+    u32x4 af[2][4];
+    Run run[2];
+    if (nsteps > 0) {
+        issue(0, 0);
+        issue(nsteps > 1 ? 1 : 0, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[0][mi] = rdA(smem, 0, mi);
+        run[0] = rdRun(smem, 0, 0);
+    }
+    // one 64-row step on stage ST: six units u = (kk, ky) of 3 (kx) x 4 (mi) MFMAs
+    auto step = [&](int s, auto ST_) {
+        constexpr int ST = decltype(ST_)::value, NX = (ST + 1) % 3, PRE = (ST + 2) % 3;
+        const char* Sb = smem + ST * STAGE;
+        const char* Nb = smem + NX * STAGE;
+        { const int s2 = s + 2 < nsteps ? s + 2 : nsteps - 1; issue(s2, PRE); }     // (past the end: a harmless re-fetch keeps the counts)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            const int kk = u / 3, ky = u - 3 * kk;
+            if (u == 5) {
+                // tile s+1 has landed (this wave's pieces; the barrier covers the others') and every wave is done with tile s's
+                // LDS reads except the ones already in its registers
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const Run c = run[u & 1];
+            if (u < 5) run[(u + 1) & 1] = rdRun(Sb, (u + 1) / 3, (u + 1) % 3);
+            else run[0] = rdRun(Nb, 0, 0);
+            if (u == 1) { af[1][0] = rdA(Sb, 1, 0); af[1][1] = rdA(Sb, 1, 1); }
+            if (u == 2) { af[1][2] = rdA(Sb, 1, 2); af[1][3] = rdA(Sb, 1, 3); }
+            u32x4 bf[3];
+            bf[0] = (u32x4){c.r0.x, c.r0.y, c.r1.x, c.r1.y};
+            bf[1] = (u32x4){__builtin_amdgcn_alignbit(c.r0.y, c.r0.x, 16), __builtin_amdgcn_alignbit(c.r1.x, c.r0.y, 16),
+                            __builtin_amdgcn_alignbit(c.r1.y, c.r1.x, 16), __builtin_amdgcn_alignbit(c.r2.x, c.r1.y, 16)};
+            bf[2] = (u32x4){c.r0.y, c.r1.x, c.r1.y, c.r2.x};
+            if (u == 5) {
+                // (the next tile's dz fragments overwrite af[0]: kk = 1 computes from af[1])
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) af[0][mi] = rdA(Nb, 0, mi);
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) mma(bf[kx], af[kk][mi], acc[ky * 3 + kx][mi]);
+                // transpose reads in flight behind each group of four MFMAs: 3 per plain unit, 7 with two dz fragments, 11 in the prefetch unit
+                if (u == 1 || u == 2) { if (kx == 0) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+                else if (u == 5) { if (kx == 2) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 4, 0); }
+                else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            if (u == 3 && do_bias && (gs0 + s) % a.tiles_ci == tile_ci) {
+                // db partial: sum_q dz[q][co] of this wave's fragment wn, both K halves of the step
+                __builtin_amdgcn_sched_barrier(0);
+                if (wn == 0) { mma(ones, af[0][0], bacc); mma(ones, af[1][0], bacc); }
+                else if (wn == 1) { mma(ones, af[0][1], bacc); mma(ones, af[1][1], bacc); }
+                else if (wn == 2) { mma(ones, af[0][2], bacc); mma(ones, af[1][2], bacc); }
+                else { mma(ones, af[0][3], bacc); mma(ones, af[1][3], bacc); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    for (int s = 0; s < nsteps; s += 3) {
+        step(s, IC2<0>{});
+        if (s + 1 < nsteps) step(s + 1, IC2<1>{});
+        if (s + 2 < nsteps) step(s + 2, IC2<2>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the over-run tiles land before the workgroup ends
+    {
+        float* P = a.partial + (((long long)split * a.co_pad) * 9) * a.ci_pad;
+        // x is the first MFMA operand: a lane holds four consecutive ci of one co -> one 16-byte store per fragment
+        const int co_b = tile_co * 128 + wm * 64 + (lane & 15);
+        const int ci_b = tile_ci * 64 + wn * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                *(f32x4*)(P + ((long long)(co_b + mi * 16) * 9 + tp) * a.ci_pad + ci_b) = acc[tp][mi];
+    }
+    if (do_bias && lane < 16)       // every row of the ones-product holds the column sum
+        a.bpartial[((long long)split * a.tiles_ci + tile_ci) * a.co_pad + tile_co * 128 + wm * 64 + wn * 16 + lane] = bacc.x;
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3, all taps per workgroup
 // For layers with few channels (Cout, Cin <= 128 at 240x240 / 120x120) the per-tap tiling above is bound by refilling
 // LDS: every tap re-reads the same dz rows and a shifted copy of the same x rows (32 FLOP per byte filled).  Here one
@@ -724,7 +927,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
 // dz pixels of the last strip that lie past the frame width are zeroed (they alias the next frame row).  Same tile (64 x 64,
 // all nine taps), fragment reads, MFMA schedule, slab layout and bias sums as wgrad3x3_kernel; the K range of a workgroup is
 // units_per_split consecutive (image, strip) units.
-template <int N> struct IC2 { static constexpr int value = N; };
 template <typename T>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs a) {
     static_assert(sizeof(T) == 2, "16-bit tiles");
@@ -1013,7 +1215,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_c8_kernel(const WgradArgs a) {
 // Fixed-order split-K reduction: partial [splits][co_pad][taps][ci_pad] -> dw [co][ci][taps] (OIHW), bpartial -> db.
 // A lane owns four consecutive ci (one 16-byte load per split); the four waves of a workgroup each sum every fourth split
 // with independent loads in flight and are combined in a fixed order through LDS, so results are bitwise repeatable.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits,
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits, int bsplits,
                                                            int co, int ci, int taps, int co_pad, int ci_pad, float* __restrict__ dw,
                                                            float* __restrict__ db, int accumulate) {
     const int c4n = ci_pad >> 2;                                       // 4-float groups per (co, tap) row
@@ -1043,7 +1245,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             for (; k < splits; k += 4) s += *(const f32x4*)(src + (long long)k * slab);
         } else if (is_b) {
             o = (int)(i - total4) * 4;
-            for (int k = g; k < splits; k += 4) {
+            for (int k = g; k < bsplits; k += 4) {
                 const float* bp = bpartial + (long long)k * co_pad + o;      // co_pad is a multiple of 64: in bounds
                 s += (f32x4){bp[0], bp[1], bp[2], bp[3]};
             }
@@ -1071,8 +1273,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3, wide; long long Q;
+struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3, wide, all9, bsplits; long long Q;
                    int strip, nstrips, units, units_per_split, spi, steps_total, steps_per_split; };
+
+static int device_cus() {            // CUs of the current device (workgroup targets of the one-round kernels)
+    static int n = 0;
+    if (!n) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; }
+    return n;
+}
 
 static int wgrad_variant() {          // DBX_WGRAD_VARIANT=1: generic per-tap kernel everywhere (A/B testing)
     static int v = -1;
@@ -1106,14 +1314,18 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
     const long long steps = (p.Q + 31) / 32;
     // aim for ~4 workgroups per CU (2 resident per CU); the c8 kernel streams dz once: 2 workgroups per CU suffice
     // row3: one 512-thread workgroup per CU, three full rounds of 256 workgroups
-    static int wgs_big = -1;                                   // DBX_WGRAD_WGS: target workgroup count of the row3 / wide kernels (A/B)
-    if (wgs_big < 0) { const char* e = getenv("DBX_WGRAD_WGS"); wgs_big = e ? atoi(e) : 768; }
+    static int wgs_big = 768;                                  // target workgroup count of the row3 / wide kernels
+#ifdef DBX_LAB
+    { static bool rd = false; if (!rd) { const char* e = getenv("DBX_WGRAD_WGS"); if (e) wgs_big = atoi(e); rd = true; } }   // lab builds: A/B
+#endif
     long long splits = ((p.row3 || p.wide ? wgs_big : p.c8 ? 512 : 1024) + tiles - 1) / tiles;
     const long long max_by_steps = steps / 16 > 0 ? steps / 16 : 1;   // at least 16 K-steps (512 rows) per split
     if (splits > max_by_steps) splits = max_by_steps;
     if (splits > (p.c8 ? 512 : 256)) splits = p.c8 ? 512 : 256;
     if (splits < 1) splits = 1;
+#ifdef DBX_LAB
     { static int ov = -1; if (ov < 0) { const char* e = getenv("DBX_WGRAD_SPLITS"); ov = e ? atoi(e) : 0; } if (ov > 0 && !p.alltaps) splits = ov; }
+#endif
     if (splits >= 8) splits = (splits + 7) / 8 * 8;           // XCD-aware workgroup mapping wants a multiple of 8
     long long sps = (steps + splits - 1) / splits;
     sps = (sps + 1) / 2 * 2;                                   // whole 64-row K steps for the R=64 kernel
@@ -1127,6 +1339,26 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
         p.steps_total = dz->n * p.spi;
         p.steps_per_split = (p.steps_total + p.splits - 1) / p.splits;
     }
+    p.all9 = 0;
+    // wide 3x3 layers, round 3: 128(co) x 64(ci) tiles over all nine taps, one workgroup per CU (DBX_WGRAD_VARIANT=20: the row3 /
+    // all-taps kernels above instead)
+    if (dtype != DBX_F32 && kh == 3 && kw == 3 && dz->c % 128 == 0 && x->c % 64 == 0 && x->c * dbx_esize(dtype) >= 128 && wgrad_variant() == 0) {
+        p.all9 = 1; p.alltaps = p.c8 = p.row3 = p.wide = 0;
+        p.bmc = 128; p.bnc = 64; p.co_pad = dz->c; p.ci_pad = x->c; p.tiles_co = dz->c / 128; p.tiles_ci = x->c / 64;
+        const int ntile = p.tiles_co * p.tiles_ci;
+        const bool compact = dz->pad == 1 && dz->w + 2 >= 32;
+        p.spi = compact ? (dz->h * (dz->w + 2) + 63) / 64 : 0;
+        const long long steps_tot = compact ? (long long)dz->n * p.spi : (p.Q + 63) / 64;
+        long long sp = device_cus() / ntile; if (sp < 1) sp = 1;
+        if (sp > steps_tot / 4) sp = steps_tot / 4 > 0 ? steps_tot / 4 : 1;       // at least four 64-row steps per split
+        if (sp >= 8) sp = sp / 8 * 8;                                              // XCD-aware workgroup mapping
+        const long long sps = (steps_tot + sp - 1) / sp;
+        p.splits = (int)((steps_tot + sps - 1) / sps);                              // no empty trailing splits
+        if (sp >= 8 && p.splits % 8) p.splits = (int)sp;                            // (keep the multiple of 8: trailing splits may be short / empty)
+        p.steps_total = compact ? (int)steps_tot : 0; p.steps_per_split = compact ? (int)sps : 0;
+        p.rows_per_split = (int)(sps * 64);
+        p.bsplits = p.splits * p.tiles_ci;
+    }
     p.strip = (p.alltaps && !p.c8 && dz->w + 2 * dz->pad >= 64 && wgrad_variant() != 11) ? 1 : 0;
     p.nstrips = p.units = p.units_per_split = 0;
     if (p.strip) {
@@ -1139,12 +1371,13 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
         p.units_per_split = (int)((p.units + want - 1) / want);
         p.splits = (p.units + p.units_per_split - 1) / p.units_per_split;
     }
+    if (!p.all9) p.bsplits = p.splits;
     return p;
 }
 
 extern "C" int64_t dbx_conv_wgrad_scratch_bytes(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw) {
     const WgradPlan p = wgrad_plan(dtype, dz, x, kh, kw);
-    return ((int64_t)p.splits * p.co_pad * p.taps * p.ci_pad + (int64_t)p.splits * p.co_pad) * 4 + 256;
+    return ((int64_t)p.splits * p.co_pad * p.taps * p.ci_pad + (int64_t)p.bsplits * p.co_pad) * 4 + 256;
 }
 
 // The kernel wgrad_t launches for this problem (one selection rule: wgrad_plan), for callers that label profiles.
@@ -1154,7 +1387,8 @@ extern "C" int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_
     if (dtype != DBX_F16 && dtype != DBX_BF16 && dtype != DBX_F32) { dbx_set_error("bad dtype %d", (int)dtype); return DBX_ERR_DTYPE; }
     const WgradPlan p = wgrad_plan(dtype, dz, x, kh, kw);
     const char* tn = dtype == DBX_F32 ? "f32" : (dtype == DBX_F16 ? "f16" : "bf16");
-    if (p.c8) snprintf(name, name_len, "wgrad3x3_c8_kernel<%s>", tn);
+    if (p.all9) snprintf(name, name_len, "wgrad_all9_kernel<%s>", tn);
+    else if (p.c8) snprintf(name, name_len, "wgrad3x3_c8_kernel<%s>", tn);
     else if (p.alltaps && p.strip) snprintf(name, name_len, "wgrad3x3_strip_kernel<%s>", tn);
     else if (p.alltaps) snprintf(name, name_len, "wgrad3x3_kernel<%s>", tn);
     else if (p.row3) snprintf(name, name_len, "wgrad_row3_kernel<%s>", tn);
@@ -1188,16 +1422,28 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.hp = a.nstrips = a.units = a.units_per_split = 0;
     a.spi = p.spi; a.img_rows = (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad); a.row0 = (dz->w + 2 * dz->pad) * dz->pad;
     a.steps_total = p.steps_total; a.steps_per_split = p.steps_per_split;
-    if (p.c8) {
+    if (p.all9) {
+        if constexpr (sizeof(T) == 2) {
+            constexpr int smem = 3 * (64 * 256 + 3 * 72 * 128);
+            static bool attr_set = false;
+            if (!attr_set) {
+                DBX_HIP(hipFuncSetAttribute((const void*)wgrad_all9_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((wgrad_all9_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a);
+        }
+    } else if (p.c8) {
         if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wgrad3x3_c8_kernel<T>), dim3(p.splits), dim3(256), 0, s, a);
     } else if (p.alltaps) {
         if constexpr (sizeof(T) == 2)
             {
                 constexpr int smem = 2 * (32 * 128 + 3 * 36 * 128);
                 static bool attr_set = false;
-                static int pad = 0;                                   // DBX_WGRAD_LDSPAD: extra dynamic LDS (occupancy experiments)
+                static int pad = 0;                                   // lab builds: DBX_WGRAD_LDSPAD = extra dynamic LDS (occupancy experiments)
                 if (!attr_set) {
+#ifdef DBX_LAB
                     const char* e = getenv("DBX_WGRAD_LDSPAD"); pad = e ? atoi(e) : 0;
+#endif
                     DBX_HIP(hipFuncSetAttribute((const void*)wgrad3x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem + pad));
                     attr_set = true;
                 }
@@ -1236,7 +1482,7 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     DBX_LAUNCH_CHECK();
     const long long total = (long long)co * p.taps * (p.ci_pad / 4) + (co + 3) / 4;
     int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, co, ci, p.taps, p.co_pad,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, p.bsplits, co, ci, p.taps, p.co_pad,
                        p.ci_pad, dw, db, accumulate);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
@@ -1247,7 +1493,7 @@ int dbx_internal_wgrad_reduce(const float* partial, const float* bpartial, int s
                               float* dw, float* db, int accumulate, hipStream_t s) {
     const long long total = (long long)co * taps * (ci_pad / 4) + (co + 3) / 4;
     int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, bpartial, splits, co, ci, taps, co_pad, ci_pad, dw, db, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, bpartial, splits, splits, co, ci, taps, co_pad, ci_pad, dw, db, accumulate);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }

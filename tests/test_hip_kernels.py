@@ -78,6 +78,8 @@ WG_CASES = [  # n, h, w, cin (view), cin real, cout, k, pad
     (2, 20, 28, 64, 64, 64, 3, 1), (2, 24, 24, 8, 3, 64, 3, 1), (3, 17, 23, 64, 64, 128, 3, 1), (2, 12, 12, 128, 128, 128, 3, 1),
     (1, 30, 30, 256, 256, 512, 3, 1), (2, 15, 15, 768, 768, 512, 1, 0), (2, 16, 16, 512, 512, 8, 1, 0),
     (3, 41, 77, 64, 64, 64, 3, 1), (2, 30, 126, 64, 64, 128, 3, 1), (5, 20, 62, 128, 100, 64, 3, 1),      # column-strip walk: ragged last strip
+    # all-nine-taps LDS-DMA ring kernel (wgrad_all9_kernel): image seams of the compact walk, several splits and ci tiles
+    (5, 30, 30, 512, 512, 512, 3, 1), (3, 60, 60, 128, 128, 256, 3, 1), (2, 120, 120, 64, 64, 128, 3, 1), (7, 30, 33, 192, 192, 128, 3, 1),
 ]
 
 
@@ -370,7 +372,8 @@ def test_forced_kernel_variants_in_subprocesses():
     import sys
     here = os.path.abspath(__file__)
     for env, sel in (({'DBX_CONV_VARIANT': '1'}, 'test_conv_forward_kernel and v1'),
-                     ({'DBX_WS': '0'}, 'test_conv_forward_kernel and dma')):
+                     ({'DBX_WS': '0'}, 'test_conv_forward_kernel and dma'),
+                     ({'DBX_WGRAD_VARIANT': '20'}, 'test_conv_wgrad_kernel')):      # the row3 / all-taps kernels behind wgrad_all9
         r = subprocess.run([sys.executable, '-m', 'pytest', here, '-x', '-q', '-m', 'gpu', '-k', sel], capture_output=True, text=True,
                            env=dict(os.environ, **env), timeout=1800)
         assert r.returncode == 0, (env, r.stdout[-3000:])
