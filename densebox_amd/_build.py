@@ -46,7 +46,8 @@ def build(force=False, verbose=True):
                     print(out, file=sys.stderr)
                 if rc != 0:
                     raise RuntimeError('hipcc failed on %s:\n%s' % (src, out))
-    if jobs or not os.path.exists(LIB):
+    stale = not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    if jobs or stale:
         cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libdensebox_hip.so')
+# DBX_LIB: load another build of the same library (tools/build_variant.sh makes same-box A/B builds of one source file)
+LIB_PATH = os.environ.get('DBX_LIB') or os.path.join(_HERE, 'csrc', 'libdensebox_hip.so')
 
 F16, BF16, F32 = 0, 1, 2
 DTYPE_ID = {'f16': F16, 'bf16': BF16, 'f32': F32}

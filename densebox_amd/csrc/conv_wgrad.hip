@@ -583,47 +583,60 @@ __global__ __launch_bounds__(512) void wgrad_all9_kernel(const WgradArgs a) {
     long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
     int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
     if (compact) { const int gs1 = min(gs0 + a.steps_per_split, a.steps_total); nsteps = gs1 > gs0 ? gs1 - gs0 : 0; }
-    auto qof = [&](int s) -> long long {
-        if (!compact) return q0 + 64LL * s;
-        const int gsx = gs0 + s, img = gsx / a.spi, j = gsx - img * a.spi;
-        return (long long)img * a.img_rows + a.row0 + 64LL * j;
-    };
 
     // ---- LDS-DMA sources.  A piece = 4 dz rows (lane: row l>>4, chunk position l&15), a B piece = 8 band rows (row l>>3, chunk
     // position l&7); position p of LDS row r receives source chunk p ^ mask(r) (swz16<128> / swz16<64>): the row bits that come
     // from the lane are folded into the lane offset, the one that comes from the piece index is a uniform XOR.
     const long long dzrow = (long long)a.dz_ld * 2, xrow = (long long)a.x_ld * 2;
-    const char* dzb = a.dz + tile_co * 256;
-    const char* xb = a.x + tile_ci * 128 + (long long)a.shift0 * (a.wp + 1) * xrow;
     const unsigned laA = (unsigned)(lane >> 4) * (unsigned)dzrow + (unsigned)(((lane & 15) ^ ((lane >> 4) << 1)) << 4);
     const unsigned laB = (unsigned)(lane >> 3) * (unsigned)xrow + (unsigned)(((lane & 7) ^ (((lane >> 4) & 1) << 1)) << 4);
+    // The tiles are issued in order, so the frame row of the next one is carried as two uniform pointers (dz, x) that advance by
+    // 64 rows, or -- compact walk, last step of an image -- by the jump to the next image's first valid row: no division and no
+    // 64-bit multiply per step.  A slot's piece is fixed for the kernel (piece = wave + 8 slot): its uniform byte offset from
+    // those pointers is computed once.
+    int ij = 0;
+    long long iq0;
+    if (compact) { const int img = gs0 / a.spi; ij = gs0 - img * a.spi; iq0 = (long long)img * a.img_rows + a.row0 + 64LL * ij; }
+    else iq0 = q0;
+    const char* ap = a.dz + tile_co * 256 + iq0 * dzrow;
+    const char* bp = a.x + tile_ci * 128 + ((long long)a.shift0 * (a.wp + 1) + iq0) * xrow;
+    const long long jump = compact ? a.img_rows - 64LL * (a.spi - 1) : 64;
+    const long long a64 = 64 * dzrow, b64 = 64 * xrow, ajmp = jump * dzrow, bjmp = jump * xrow;
+    // piece of slot i = wave + 8 i: slots 0, 1 are dz pieces, 2 .. 5 band pieces (slot 5 of waves 3 .. 7 repeats their slot 4:
+    // every wave issues SLOTS loads, the waits are counted).  The swizzle bit that comes from the piece index depends on the wave
+    // only -> folded into the lane offsets; the row offsets of the slots are six uniform constants.
+    static_assert(AP == 16 && NPIECE == 43 && SLOTS == 6, "slot layout");
+    const unsigned vA = laA ^ (unsigned)(((wave >> 1) & 1) << 7), vB = laB ^ (unsigned)((wave & 1) << 6);
+    const int pb5 = wave < 3 ? wave + 24 : wave + 16;
+    auto boff = [&](int pb) { const int band = pb / 9, pr = pb - band * 9; return (unsigned)(band * a.wp + 8 * pr) * (unsigned)xrow; };
+    const unsigned sA0 = (unsigned)(4 * wave) * (unsigned)dzrow, sA1 = sA0 + 32u * (unsigned)dzrow;
+    const unsigned sB2 = boff(wave), sB3 = boff(wave + 8), sB4 = boff(wave + 16), sB5 = boff(pb5);
     // The DMA goes out as inline asm (saddr form: uniform base + one lane offset register): for the builtin the compiler's
     // waitcnt pass puts s_waitcnt vmcnt(0) in front of the next transpose read (it cannot prove that the ds_read_tr intrinsic
     // does not alias the LDS-DMA destination), which drains the ring every step.  Invisible to that pass, the loads are counted by
     // hand: the only other VMEM operations of the kernel are the slab stores behind the final vmcnt(0).
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue = [&](int s, int stage) {
-        const long long qs = qof(s);
-#pragma unroll
-        for (int i = 0; i < SLOTS; ++i) {
-            int pid = wave + 8 * i;
-            if (pid >= NPIECE) pid -= 8;                                // (uniform) every wave issues SLOTS loads: counted waits
-            const char* src;
-            unsigned voff;
-            if (pid < AP) {
-                src = dzb + (qs + 4 * pid) * dzrow;
-                voff = laA ^ (unsigned)(((pid >> 1) & 1) << 7);
-            } else {
-                const int pb = pid - AP, band = pb / 9, pr = pb - band * 9;
-                src = xb + (qs + (long long)band * a.wp + 8 * pr) * xrow;
-                voff = laB ^ (unsigned)((pb & 1) << 6);
-            }
-            const unsigned dst = lds0 + stage * STAGE + pid * 1024;
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
-        }
+    const unsigned ldsw = lds0 + wave * 1024, lds5 = lds0 + (AP + pb5) * 1024;
+    int issued = 0;
+    auto glds = [](const char* src, unsigned voff, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
     };
+    // issue the next tile into the stage at byte offset sb (the last tile again past the end: keeps the counts), then advance
+#define ALL9_ISSUE(sb)                                                                      \
+    do {                                                                                    \
+        glds(ap + sA0, vA, ldsw + (sb));                                                    \
+        glds(ap + sA1, vA, ldsw + (sb) + 8 * 1024);                                         \
+        glds(bp + sB2, vB, ldsw + (sb) + 16 * 1024);                                        \
+        glds(bp + sB3, vB, ldsw + (sb) + 24 * 1024);                                        \
+        glds(bp + sB4, vB, ldsw + (sb) + 32 * 1024);                                        \
+        glds(bp + sB5, vB, lds5 + (sb));                                                    \
+        if (++issued < nsteps) {                                                            \
+            if (compact && ++ij == a.spi) { ij = 0; ap += ajmp; bp += bjmp; }               \
+            else { ap += a64; bp += b64; }                                                  \
+        }                                                                                   \
+    } while (0)
 
     f32x4 acc[9][4];
 #pragma unroll
@@ -662,8 +675,8 @@ __global__ __launch_bounds__(512) void wgrad_all9_kernel(const WgradArgs a) {
     u32x4 af[2][4];
     Run run[2];
     if (nsteps > 0) {
-        issue(0, 0);
-        issue(nsteps > 1 ? 1 : 0, 1);
+        ALL9_ISSUE(0u);
+        ALL9_ISSUE((unsigned)STAGE);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -671,12 +684,13 @@ __global__ __launch_bounds__(512) void wgrad_all9_kernel(const WgradArgs a) {
         for (int mi = 0; mi < 4; ++mi) af[0][mi] = rdA(smem, 0, mi);
         run[0] = rdRun(smem, 0, 0);
     }
-    // one 64-row step on stage ST: six units u = (kk, ky) of 3 (kx) x 4 (mi) MFMAs
-    auto step = [&](int s, auto ST_) {
-        constexpr int ST = decltype(ST_)::value, NX = (ST + 1) % 3, PRE = (ST + 2) % 3;
-        const char* Sb = smem + ST * STAGE;
-        const char* Nb = smem + NX * STAGE;
-        { const int s2 = s + 2 < nsteps ? s + 2 : nsteps - 1; issue(s2, PRE); }     // (past the end: a harmless re-fetch keeps the counts)
+    // one 64-row step per iteration: six units u = (kk, ky) of 3 (kx) x 4 (mi) MFMAs; the stages rotate as uniform byte offsets
+    unsigned so = 0, no = STAGE, po = 2 * STAGE;                        // this tile's stage, the next tile's, the one tile s + 2 goes to
+    int bctr = gs0 % a.tiles_ci;                                        // the ci tile that owns this step's bias sums
+    for (int s = 0; s < nsteps; ++s) {
+        const char* Sb = smem + so;
+        const char* Nb = smem + no;
+        ALL9_ISSUE(po);                                                 // tile s + 2
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
@@ -714,7 +728,7 @@ __global__ __launch_bounds__(512) void wgrad_all9_kernel(const WgradArgs a) {
                 else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
             }
-            if (u == 3 && do_bias && (gs0 + s) % a.tiles_ci == tile_ci) {
+            if (u == 3 && do_bias && bctr == tile_ci) {
                 // db partial: sum_q dz[q][co] of this wave's fragment wn, both K halves of the step
                 __builtin_amdgcn_sched_barrier(0);
                 if (wn == 0) { mma(ones, af[0][0], bacc); mma(ones, af[1][0], bacc); }
@@ -724,23 +738,20 @@ __global__ __launch_bounds__(512) void wgrad_all9_kernel(const WgradArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-    };
-    for (int s = 0; s < nsteps; s += 3) {
-        step(s, IC2<0>{});
-        if (s + 1 < nsteps) step(s + 1, IC2<1>{});
-        if (s + 2 < nsteps) step(s + 2, IC2<2>{});
+        if (++bctr == a.tiles_ci) bctr = 0;
+        { const unsigned t3 = so; so = no; no = po; po = t3; }
     }
+#undef ALL9_ISSUE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the over-run tiles land before the workgroup ends
     {
-        float* P = a.partial + (((long long)split * a.co_pad) * 9) * a.ci_pad;
-        // x is the first MFMA operand: a lane holds four consecutive ci of one co -> one 16-byte store per fragment
-        const int co_b = tile_co * 128 + wm * 64 + (lane & 15);
-        const int ci_b = tile_ci * 64 + wn * 16 + (lane >> 4) * 4;
+        // slab = the accumulator registers as they are: [split][tile][wave][tap][mi][lane][4 ci] -- every store instruction writes
+        // 1 KiB of consecutive bytes; wgrad_reduce_all9_kernel maps (wave, tap, mi, lane) back to (co, tap, ci)
+        float* P = a.partial + (((long long)split * (a.tiles_co * a.tiles_ci) + t) * 8 + wave) * (36 * 256) + lane * 4;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
-                *(f32x4*)(P + ((long long)(co_b + mi * 16) * 9 + tp) * a.ci_pad + ci_b) = acc[tp][mi];
+                *(f32x4*)(P + (tp * 4 + mi) * 256) = acc[tp][mi];
     }
     if (do_bias && lane < 16)       // every row of the ones-product holds the column sum
         a.bpartial[((long long)split * a.tiles_ci + tile_ci) * a.co_pad + tile_co * 128 + wm * 64 + wn * 16 + lane] = bacc.x;
@@ -1272,6 +1283,72 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// Split reduction for wgrad_all9_kernel's slabs (register dumps [split][tile][wave][tap * 4 + mi][lane][4]): a workgroup owns 64
+// consecutive 16-byte elements of a slab (one fragment of one wave), its four waves sum every fourth split with coalesced 1-KiB
+// loads and are combined in a fixed order through LDS (bitwise repeatable); element -> (co, tap, ci .. ci+3) -> fp32 OIHW.
+// Bias: bpartial [bsplits][co_pad], summed the same way by the workgroups past the last slab element.
+__global__ __launch_bounds__(256) void wgrad_reduce_all9_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits,
+                                                                int bsplits, int co, int ci, int tiles_co, int tiles_ci, int co_pad,
+                                                                float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+    const int ntile = tiles_co * tiles_ci;
+    const long long total4 = (long long)ntile * 8 * 36 * 64;            // 16-byte elements per slab
+    const long long nb = (co + 3) / 4;
+    const long long slab4 = total4;
+    const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
+    __shared__ f32x4 red[4][64];
+    for (long long base = (long long)blockIdx.x * 64; base < total4 + nb; base += (long long)gridDim.x * 64) {
+        const long long i = base + e;
+        const bool is_w = i < total4, is_b = !is_w && i < total4 + nb && db != nullptr;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (is_w) {
+            const f32x4* src = (const f32x4*)partial + i;
+            int k = g;
+            for (; k + 12 < splits; k += 16) {
+                const f32x4 v0 = src[(long long)k * slab4], v1 = src[(long long)(k + 4) * slab4];
+                const f32x4 v2 = src[(long long)(k + 8) * slab4], v3 = src[(long long)(k + 12) * slab4];
+                s += (v0 + v1) + (v2 + v3);
+            }
+            for (; k < splits; k += 4) s += src[(long long)k * slab4];
+        } else if (is_b) {
+            const int o = (int)(i - total4) * 4;
+            for (int k = g; k < bsplits; k += 4) {
+                const float* bq = bpartial + (long long)k * co_pad + o;  // co_pad is a multiple of 128: in bounds
+                s += (f32x4){bq[0], bq[1], bq[2], bq[3]};
+            }
+        }
+        red[g][e] = s;
+        __syncthreads();
+        if (g == 0 && (is_w || is_b)) {
+            const f32x4 v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            if (is_w) {
+                const int lane = (int)(i & 63);
+                long long r = i >> 6;
+                const int f = (int)(r % 36); r /= 36;
+                const int wave = (int)(r & 7); r >>= 3;
+                const int tile = (int)r, tile_ci = tile % tiles_ci, tile_co = tile / tiles_ci;
+                const int tp = f >> 2, mi = f & 3;
+                const int o = tile_co * 128 + (wave >> 2) * 64 + mi * 16 + (lane & 15);
+                const int c = tile_ci * 64 + (wave & 3) * 16 + (lane >> 4) * 4;
+                if (o < co) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c + j < ci) {
+                            float* out = dw + ((long long)o * ci + c + j) * 9 + tp;
+                            *out = accumulate ? *out + vv[j] : vv[j];
+                        }
+                }
+            } else {
+                const int o = (int)(i - total4) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (o + j < co) db[o + j] = accumulate ? db[o + j] + vv[j] : vv[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3, wide, all9, bsplits; long long Q;
                    int strip, nstrips, units, units_per_split, spi, steps_total, steps_per_split; };
@@ -1480,6 +1557,14 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
         else hipLaunchKernelGGL((wgrad_kernel<T, 64, 64>), grid, dim3(256), 0, s, a);
     }
     DBX_LAUNCH_CHECK();
+    if (p.all9) {
+        const long long total = (long long)p.tiles_co * p.tiles_ci * 8 * 36 * 64 + (co + 3) / 4;
+        int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
+        hipLaunchKernelGGL(wgrad_reduce_all9_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, p.bsplits, co, ci, p.tiles_co,
+                           p.tiles_ci, p.co_pad, dw, db, accumulate);
+        DBX_LAUNCH_CHECK();
+        return DBX_OK;
+    }
     const long long total = (long long)co * p.taps * (p.ci_pad / 4) + (co + 3) / 4;
     int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, p.bsplits, co, ci, p.taps, p.co_pad,
