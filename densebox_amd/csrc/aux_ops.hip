@@ -415,6 +415,103 @@ __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(FrameGeo dy, Fra
         store_vec<T>((T*)dx.base + geo_pix(dx, n, iy, ix) + g * V, acc);
     }
 }
+// Wide maps (round 3: the 2048-channel hidden gradient, 944 MB): one workgroup per PAIR of source rows, one thread per 16-byte
+// channel group.  A thread walks the destination columns once: per column it loads the <= 8 destination rows that interpolate
+// from either source row (each element exactly once per workgroup, 4 KiB contiguous per load instruction across the workgroup),
+// reduces them over y with the two rows' weights, and adds the result to two rolling accumulators per source row (the columns
+// x0 and x0 + 1 it interpolates from); an accumulator is stored when the walk leaves its column.  Same coefficients as the
+// forward (bilin_coef), fp32 accumulation, y before x.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_walk_kernel(FrameGeo dy, FrameGeo dx, FrameGeo gate, int has_gate, float sy, float sx, int pairs) {
+    constexpr int V = Vec<T>::N, MAXR = 8;
+    extern __shared__ __attribute__((aligned(16))) char up_smem[];
+    int* s_x0 = (int*)up_smem;                          // [dy.w] first source column of destination column ox
+    float* s_l0 = (float*)(s_x0 + dy.w);                // [dy.w] weight of source column x0 (both weights when x1 == x0)
+    float* s_l1 = s_l0 + dy.w;                          // [dy.w] weight of source column x0 + 1 (0 when x1 == x0)
+    __shared__ int s_oy[MAXR];
+    __shared__ float s_w[2][MAXR];
+    __shared__ int s_ny;
+    // workgroup b runs on XCD b % 8: give every XCD a contiguous range of row pairs (neighbouring pairs share destination rows)
+    const int nwg = gridDim.x;
+    int b = blockIdx.x;
+    { const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, j = b >> 3; b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j; }
+    const int n = b / pairs, iy0 = 2 * (b - n * pairs);
+    const bool two = iy0 + 1 < dx.h;
+    if (threadIdx.x == 0) {
+        const int iy1 = two ? iy0 + 1 : iy0;
+        int lo = sy > 0.f ? (int)floorf((float)(iy0 - 1) / sy) : 0, hi = sy > 0.f ? (int)ceilf((float)(iy1 + 1) / sy) : dy.h - 1;
+        lo = max(lo, 0); hi = min(hi, dy.h - 1);
+        int cnt = 0;
+        for (int oy = lo; oy <= hi && cnt < MAXR; ++oy) {
+            int y0, y1; float ly0, ly1;
+            bilin_coef(oy, sy, dx.h, y0, y1, ly0, ly1);
+            const float wa = (y0 == iy0 ? ly0 : 0.f) + (y1 == iy0 ? ly1 : 0.f);
+            const float wb = two ? (y0 == iy0 + 1 ? ly0 : 0.f) + (y1 == iy0 + 1 ? ly1 : 0.f) : 0.f;
+            if (wa != 0.f || wb != 0.f) { s_oy[cnt] = oy; s_w[0][cnt] = wa; s_w[1][cnt] = wb; ++cnt; }
+        }
+        s_ny = cnt;
+    }
+    for (int ox = threadIdx.x; ox < dy.w; ox += 256) {
+        int x0, x1; float lx0, lx1;
+        bilin_coef(ox, sx, dx.w, x0, x1, lx0, lx1);
+        s_x0[ox] = x0; s_l0[ox] = x1 == x0 ? lx0 + lx1 : lx0; s_l1[ox] = x1 == x0 ? 0.f : lx1;
+    }
+    __syncthreads();
+    const int ny = s_ny, cg = dx.c / V;
+    const int dys = (int)(geo_pix(dy, n, 0, 1) - geo_pix(dy, n, 0, 0)), dxs = (int)(geo_pix(dx, n, 0, 1) - geo_pix(dx, n, 0, 0));
+    for (int g = threadIdx.x; g < cg; g += 256) {
+        const T* rows[MAXR];
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) rows[r] = (const T*)dy.base + geo_pix(dy, n, s_oy[r < ny ? r : 0], 0) + g * V;
+        T* out0 = (T*)dx.base + geo_pix(dx, n, iy0, 0) + g * V;
+        T* out1 = (T*)dx.base + geo_pix(dx, n, two ? iy0 + 1 : iy0, 0) + g * V;
+        const T* gt0 = (const T*)gate.base + geo_pix(gate, n, iy0, 0) + g * V;
+        const T* gt1 = (const T*)gate.base + geo_pix(gate, n, two ? iy0 + 1 : iy0, 0) + g * V;
+        const int gts = (int)(geo_pix(gate, n, 0, 1) - geo_pix(gate, n, 0, 0));
+        float c0[V], c1[V], n0[V], n1[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) c0[j] = c1[j] = n0[j] = n1[j] = 0.f;
+        auto flush = [&](int col, float (&a0)[V], float (&a1)[V]) {
+            if (has_gate) {
+                float ga[V], gb[V];
+                load_vec<T>(gt0 + (size_t)col * gts, ga); load_vec<T>(gt1 + (size_t)col * gts, gb);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { a0[j] = ga[j] > 0.f ? a0[j] : 0.f; a1[j] = gb[j] > 0.f ? a1[j] : 0.f; }
+            }
+            store_vec<T>(out0 + (size_t)col * dxs, a0);
+            if (two) store_vec<T>(out1 + (size_t)col * dxs, a1);
+        };
+        int cur = s_x0[0];
+        for (int ox = 0; ox < dy.w; ++ox) {
+            const int x0 = s_x0[ox];
+            const float l0 = s_l0[ox], l1 = s_l1[ox];
+            if (x0 != cur) {                                          // (uniform) the walk left column `cur`
+                flush(cur, c0, c1);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { c0[j] = n0[j]; c1[j] = n1[j]; n0[j] = 0.f; n1[j] = 0.f; }
+                cur = x0;
+            }
+            float v0[V], v1[V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) v0[j] = v1[j] = 0.f;
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                if (r < ny) {
+                    float d[V];
+                    load_vec<T>(rows[r] + (size_t)ox * dys, d);
+                    const float wa = s_w[0][r], wb = s_w[1][r];
+#pragma unroll
+                    for (int j = 0; j < V; ++j) { v0[j] += wa * d[j]; v1[j] += wb * d[j]; }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < V; ++j) { c0[j] += l0 * v0[j]; c1[j] += l0 * v1[j]; n0[j] += l1 * v0[j]; n1[j] += l1 * v1[j]; }
+        }
+        flush(cur, c0, c1);
+        if (cur + 1 < dx.w) flush(cur + 1, n0, n1);
+    }
+}
+
 template <typename T>
 static int upsample_bwd_t(const dbx_view* dy, const dbx_view* dx, const dbx_view* gate, hipStream_t s) {
     VIEW_VEC_CHECK(T, dy, "upsample_bwd dy"); VIEW_VEC_CHECK(T, dx, "upsample_bwd dx");
@@ -423,9 +520,17 @@ static int upsample_bwd_t(const dbx_view* dy, const dbx_view* dx, const dbx_view
     const int64_t total = (int64_t)dx->n * dx->h * dx->w * (dx->c / Vec<T>::N);
     FrameGeo gg = gate ? make_geo<T>(gate) : make_geo<T>(dx);
     const float sy = ac_scale(dx->h, dy->h), sx = ac_scale(dx->w, dy->w);
-    // the tabulated kernel covers up-sampling factors up to ~3 (<= 8 destination columns and <= 16 rows per source pixel)
-    const bool rows_ok = sy > 0.34f && sx > 0.34f && dx->w <= 2048;
-    if (rows_ok)
+    // up-sampling by ~2 (every destination column interpolates from x0 and x0 + 1 with x0 non-decreasing, <= 8 destination rows per
+    // source-row pair) on maps with >= 64 channel groups: the column walk
+    const bool walk_ok = sy > 0.45f && sy < 1.f && sx > 0.45f && sx < 1.f && dx->c / Vec<T>::N >= 64 && dy->w <= 4096;
+    // the tabulated kernel covers up-sampling factors up to ~3 (<= 8 destination columns and <= 16 rows per source pixel); its
+    // table (36 B per source column) stays inside the 64 KB of dynamic LDS a launch gets without an attribute
+    const bool rows_ok = sy > 0.34f && sx > 0.34f && dx->w <= 1536;
+    if (walk_ok) {
+        const int pairs = (dx->h + 1) / 2;
+        hipLaunchKernelGGL(upsample_bwd_walk_kernel<T>, dim3(dx->n * pairs), dim3(256), (size_t)dy->w * 12, s, make_geo<T>(dy), make_geo<T>(dx), gg,
+                           gate ? 1 : 0, sy, sx, pairs);
+    } else if (rows_ok)
         hipLaunchKernelGGL(upsample_bwd_rows_kernel<T>, dim3(dx->n * dx->h), dim3(256), (size_t)dx->w * (4 + 8 * 4), s, make_geo<T>(dy), make_geo<T>(dx), gg,
                            gate ? 1 : 0, sy, sx);
     else
@@ -858,7 +963,7 @@ extern "C" int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const db
 // One launch re-packs every parameter after an optimizer step (fp32 OIHW -> compute-dtype GEMM layouts, both the forward
 // and the transposed/flipped dgrad copy) and refreshes the padded fp32 bias vectors.  Same element mapping as
 // dbx_pack_weight (conv_igemm.hip); the table lives in device memory and is built once by the host.
-struct PackJob { const float* src; void* dst; int co, ci, taps, mode; long long ktot; int cin_pad, row_off, k_off; };
+struct PackJob { const float* src; void* dst; int co, ci, taps, mode; long long ktot; int cin_pad, row_off, k_off, rows_lim; };   // rows_lim: rows of dst (0: not checked)
 template <typename T>
 __global__ void pack_multi_kernel(const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
@@ -869,6 +974,12 @@ __global__ void pack_multi_kernel(const PackJob* __restrict__ jobs) {
         if (j.mode == 2) { ((float*)j.dst)[j.row_off + i] = v; continue; }        // bias: plain copy into the padded vector
         const int q = i / taps, t = i - q * taps;
         const int o = q / ci, c = q - o * ci;
+        {   // an element whose destination lies outside the packed matrix is skipped: negative offsets cut a channel range out of a wider tensor
+            const bool fwd = j.mode == 0 || j.mode == 4;
+            const int row = j.row_off + (fwd ? o : c), col = j.k_off + (fwd ? c : o);
+            const int rl = j.mode >= 4 ? (int)j.ktot : j.rows_lim;
+            if (row < 0 || col < 0 || col >= j.cin_pad || (rl > 0 && row >= rl)) continue;
+        }
         if (j.mode == 0) wp[(long long)(j.row_off + o) * j.ktot + (long long)t * j.cin_pad + j.k_off + c] = from_f32<T>(v);
         else if (j.mode == 1) wp[(long long)(j.row_off + c) * j.ktot + (long long)(taps - 1 - t) * j.cin_pad + j.k_off + o] = from_f32<T>(v);
         else if (j.mode == 4) wp[dbx_frag_index(j.row_off + o, t, j.k_off + c, j.cin_pad, (int)j.ktot, taps)] = from_f32<T>(v);

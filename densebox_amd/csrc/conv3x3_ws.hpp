@@ -84,15 +84,16 @@ struct WsArgs {
     int hwp;             // H * Wp: q' per image
     int qtot;            // N * H * Wp
     int xpad;            // frame width of x (1; 0 for an unframed 1x1 input): halo columns fx < xpad, fx >= Wp - xpad are dropped
-#ifdef DBX_LAB
-    int dbg;             // DBX_WS_DBG (lab builds only): 1 no periods, 2 no stores, 4 no band DMA, 8 no weight loads
-#endif
+    int dbg;             // ablation bits (lab builds: DBX_WS_DBG = 1 no periods, 2 no stores, 4 no band DMA, 8 no weight loads); 0 in the product library
 };
-// ablation bits: a run-time field in lab builds (tools/band_lab.hip), the constant 0 in the product library (the tests fold away)
+// Lab builds (tools/band_lab.hip) read the bits from the environment.  The product library never does: the 3x3 instantiations see
+// the constant 0 (their tests fold away: 225 -> 208 us per conv4 layer), the 1x1 instantiations keep testing the field, which the
+// host always sets to 0 -- with the tests folded away the compiler schedules the heads' epilogue 25 % slower (same-box A/B:
+// heads forward 901 -> 1165 us, its split data gradient 665 -> 770 us), so the dead tests stay as a code-generation anchor.
 #ifdef DBX_LAB
 #define WS_DBG(t) ((t).dbg)
 #else
-#define WS_DBG(t) 0
+#define WS_DBG(t) (KS == 1 ? (t).dbg : 0)
 #endif
 
 // EPIK: 0 = the epilogue reads its kind from the arguments at run time; 1 = fixed to BIAS + hash dropout on a single destination
@@ -442,6 +443,7 @@ static inline WsArgs ws_schedule(long long qtot, int hwp, int wm, int ntile_n, i
     }
     t.mt = (int)mt; t.base = (int)(units / mt); t.extra = (int)(units % mt);
     t.items = (int)(mt * ntile_n); t.hwp = hwp; t.qtot = (int)qtot; t.xpad = xpad;
+    t.dbg = 0;
 #ifdef DBX_LAB
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DBX_WS_DBG"); dbg = e ? atoi(e) : 0; } t.dbg = dbg; }
 #endif

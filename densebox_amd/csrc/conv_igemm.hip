@@ -1404,11 +1404,11 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
                      !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK | DBX_EPI_ACCUM)) && (k1 || !(d->epilogue & DBX_EPI_DROPHASH)) &&
                      (k1 || !y2) && d->cin_pad % 64 == 0 && d->cin_pad >= 128 && ctot == d->cout_pad && d->cout_pad % 128 == 0 &&
                      (x->c_off * ES) % 128 == 0 && (y->c_off * ES) % 16 == 0 && (y->ld * ES) % 16 == 0;
-        {   // the kernel's epilogue kinds: plain / ReLU / ReLU-gate (3x3), plain / hash dropout / plain + gated second destination (1x1)
+        {   // the kernel's epilogue kinds: plain / ReLU / ReLU-gate (3x3), plain / hash dropout / ReLU-gate / plain + gated second destination (1x1)
             const int kk = d->epilogue & (DBX_EPI_RELU | DBX_EPI_GATE | DBX_EPI_DROPHASH);
             if (y2) ws_ok = ws_ok && kk == 0 && (epi2 & (DBX_EPI_RELU | DBX_EPI_GATE | DBX_EPI_DROPHASH | DBX_EPI_BIAS)) == DBX_EPI_GATE;
             else if (k3) ws_ok = ws_ok && (kk == 0 || kk == DBX_EPI_RELU || kk == DBX_EPI_GATE);
-            else ws_ok = ws_ok && (kk == 0 || kk == DBX_EPI_DROPHASH);
+            else ws_ok = ws_ok && (kk == 0 || kk == DBX_EPI_DROPHASH || kk == DBX_EPI_GATE);
         }
         if (ws_ok && y2) ws_ok = split_c % 256 == 0 && y2->c % 256 == 0 && !(epi2 & DBX_EPI_ACCUM) && (y2->c_off * ES) % 16 == 0 && (y2->ld * ES) % 16 == 0;
         const int wm = d->cout_pad % 256 == 0 ? 1 : 2;
@@ -1625,6 +1625,11 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int co, int ci, 
         const int c = (int)((i / taps) % ci);
         const int o = (int)(i / ((int64_t)taps * ci));
         const float v = w[i];
+        {   // an element whose destination lies outside the packed matrix is skipped: negative offsets cut a channel range out of a wider tensor
+            const bool fwd = mode == 0 || mode == 4;
+            const int row = row_off + (fwd ? o : c), col = k_off + (fwd ? c : o);
+            if (row < 0 || row >= rows_pad || col < 0 || col >= cin_pad) continue;
+        }
         if (mode == 0) wp[(int64_t)(row_off + o) * ktot + (int64_t)t * cin_pad + k_off + c] = from_f32<T>(v);
         else if (mode == 1) wp[(int64_t)(row_off + c) * ktot + (int64_t)(taps - 1 - t) * cin_pad + k_off + o] = from_f32<T>(v);
         else if (mode == 4) wp[dbx_frag_index(row_off + o, t, k_off + c, cin_pad, rows_pad, taps)] = from_f32<T>(v);
@@ -1638,9 +1643,7 @@ static int pack_weight_t(int mode, const float* w, int co, int ci, int kh, int k
     dbx_conv_desc d; d.dtype = DType<T>::id; d.kh = kh; d.kw = kw; d.cin_pad = cin_pad; d.cout_pad = rows_pad; d.drop_seed = 0;
     const int64_t ktot = packed_k_elems(&d);
     DBX_REQUIRE(mode == 0 || mode == 1 || mode == 4 || mode == 5, "pack_weight: mode %d", mode);
-    const bool fwd = mode == 0 || mode == 4;
-    const int rows = fwd ? co : ci, cols = fwd ? ci : co;
-    DBX_REQUIRE(row_off + rows <= rows_pad && k_off + cols <= cin_pad, "pack_weight: slice out of range");
+    // (rows / columns that fall outside [0, rows_pad) x [0, cin_pad) are skipped: a negative row_off / k_off packs a channel range)
     if (mode >= 4) DBX_REQUIRE(sizeof(T) == 2 && ((kh == 3 && kw == 3 && rows_pad % 128 == 0 && cin_pad % 64 == 0) ||
                                                  (kh == 1 && kw == 1 && rows_pad % 256 == 0 && cin_pad % 128 == 0)),
                                "pack_weight: fragment order needs a 16-bit 3x3 layer (rows_pad %% 128, cin_pad %% 64) or 1x1 layer (rows_pad %% 256, cin_pad %% 128)");

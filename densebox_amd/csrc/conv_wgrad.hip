@@ -757,6 +757,174 @@ __global__ __launch_bounds__(512) void wgrad_all9_kernel(const WgradArgs a) {
         a.bpartial[((long long)split * a.tiles_ci + tile_ci) * a.co_pad + tile_co * 128 + wm * 64 + wn * 16 + lane] = bacc.x;
 }
 
+// ------------------------------------------------------------------------------------------------ wide 1x1 layers, round 3: LDS-DMA ring
+// The heads' weight gradients (2048 couts x 512 / 256 input channels) with wgrad_all9_kernel's pipeline: 256(co) x 256(ci)
+// tile, 8 waves as 4(co) x 2(ci) (64 x 128 per wave, 4 x 8 accumulator fragments), 32-row K steps, FOUR 32-KB stages (dz tile +
+// x tile, 32 rows x 512 B each) filled by inline-asm LDS-DMA: tile s+3 is issued behind the barrier of step s (into the stage
+// tile s-1 has left), tile s+1 is waited for (counted vmcnt) in front of it, and the barrier sits in front of the step's last
+// three units, under which the next step's first fragments are read.  One workgroup per CU (256 workgroups, one round): the
+// slab is the register dump (67 MB instead of 201 MB for the 768-workgroup wgrad_wide_kernel).  Compact walk over the valid
+// rows of each image (a 1x1 tap needs no halo rows).  The bias partial comes from ones-MFMAs of the waves' dz fragments (wave
+// column wn takes fragments 2 wn, 2 wn + 1) in the steps assigned to the workgroup's ci tile.
+// Requires dz_c % 256 == 0, x_c % 256 == 0.  Grid: (co-tile, ci-tile) x split-K; bias partial rows = splits * tiles_ci.
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_wide2_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit tiles");
+    constexpr int R = 32, T_BYTES = R * 512, STAGE = 2 * T_BYTES, NST = 4;
+    constexpr int SLOTS = 4;                                            // 32 pieces of 1 KiB (2 rows) per stage, 8 waves
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // 4 x 32 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                           // wave tile 64(co) x 128(ci)
+    int t, split;
+    wg_tile_split(a.tiles_co * a.tiles_ci, a.nsplit, t, split);
+    const int tile_ci = t % a.tiles_ci, tile_co = t / a.tiles_ci;
+    const bool compact = a.spi > 0;
+    const int gs0 = compact ? split * a.steps_per_split : (int)(((long long)split * a.rows_per_split) / R);
+    const long long q0 = compact ? 0 : (long long)split * a.rows_per_split;
+    long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
+    int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
+    if (compact) { const int gs1 = min(gs0 + a.steps_per_split, a.steps_total); nsteps = gs1 > gs0 ? gs1 - gs0 : 0; }
+
+    // ---- LDS-DMA sources: a piece = 2 rows x 512 B (lane: row l>>5, chunk position l&31); position p of LDS row r receives source
+    // chunk p ^ ((r & 3) << 1 | ((r >> 3) & 1) << 3) (swz16w); with piece = wave + 8 slot the piece-dependent bits depend on the wave only
+    const long long dzrow = (long long)a.dz_ld * 2, xrow = (long long)a.x_ld * 2;
+    const unsigned chunk = (unsigned)((lane & 31) ^ ((lane >> 5) << 1) ^ ((wave & 1) << 2) ^ (((wave >> 2) & 1) << 3));
+    const unsigned vA = (unsigned)(lane >> 5) * (unsigned)dzrow + (chunk << 4), vB = (unsigned)(lane >> 5) * (unsigned)xrow + (chunk << 4);
+    int ij = 0;
+    long long iq0;
+    if (compact) { const int img = gs0 / a.spi; ij = gs0 - img * a.spi; iq0 = (long long)img * a.img_rows + a.row0 + (long long)R * ij; }
+    else iq0 = q0;
+    const long long xshift = (long long)a.shift0 * (a.wp + 1);         // 1x1: tap (0, 0)
+    const char* ap = a.dz + tile_co * 512 + iq0 * dzrow;
+    const char* bp = a.x + tile_ci * 512 + (xshift + iq0) * xrow;
+    const long long jump = compact ? a.img_rows - (long long)R * (a.spi - 1) : R;
+    const long long aR = R * dzrow, bR = R * xrow, ajmp = jump * dzrow, bjmp = jump * xrow;
+    const unsigned sA0 = (unsigned)(2 * wave) * (unsigned)dzrow, sA1 = sA0 + 16u * (unsigned)dzrow;
+    const unsigned sB0 = (unsigned)(2 * wave) * (unsigned)xrow, sB1 = sB0 + 16u * (unsigned)xrow;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = lds0 + wave * 1024;
+    int issued = 0;
+    auto glds = [](const char* src, unsigned voff, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+    };
+#define WIDE2_ISSUE(sb)                                                                     \
+    do {                                                                                    \
+        glds(ap + sA0, vA, ldsw + (sb));                                                    \
+        glds(ap + sA1, vA, ldsw + (sb) + 8 * 1024);                                         \
+        glds(bp + sB0, vB, ldsw + (sb) + T_BYTES);                                          \
+        glds(bp + sB1, vB, ldsw + (sb) + T_BYTES + 8 * 1024);                               \
+        if (++issued < nsteps) {                                                            \
+            if (compact && ++ij == a.spi) { ij = 0; ap += ajmp; bp += bjmp; }               \
+            else { ap += aR; bp += bR; }                                                    \
+        }                                                                                   \
+    } while (0)
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 8; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const unsigned one2 = DType<T>::id == DBX_F16 ? 0x3C003C00u : 0x3F803F80u;
+    const u32x4 ones = {one2, one2, one2, one2};
+    const bool do_bias = a.bpartial != nullptr;
+
+    const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
+    auto trd = [&](const char* p) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
+    };
+    auto rdA = [&](const char* Sb, int mi) {
+        const int r0 = 8 * g + rsub, cbyte = (wm * 64 + mi * 16) * 2 + csub;
+        const u32x2 lo = trd(Sb + swz16w(r0, cbyte)), hi = trd(Sb + swz16w(r0 + 4, cbyte));
+        return (u32x4){lo.x, lo.y, hi.x, hi.y};
+    };
+    auto rdB = [&](const char* Sb, int ni) {
+        const int r0 = 8 * g + rsub, cbyte = (wn * 128 + ni * 16) * 2 + csub;
+        const u32x2 lo = trd(Sb + T_BYTES + swz16w(r0, cbyte)), hi = trd(Sb + T_BYTES + swz16w(r0 + 4, cbyte));
+        return (u32x4){lo.x, lo.y, hi.x, hi.y};
+    };
+    auto mma = [&](const u32x4& xf, const u32x4& zf, f32x4& c) {
+        if constexpr (DType<T>::id == DBX_F16)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf), __builtin_bit_cast(f16x8, zf), c, 0, 0, 0);
+        else
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, zf), c, 0, 0, 0);
+    };
+
+    u32x4 af[2][4], bf[2];
+    if (nsteps > 0) {
+        WIDE2_ISSUE(0u);
+        WIDE2_ISSUE((unsigned)STAGE);
+        WIDE2_ISSUE((unsigned)(2 * STAGE));
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SLOTS) : "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[0][mi] = rdA(smem, mi);
+        bf[0] = rdB(smem, 0);
+    }
+    // one 32-row step per iteration: eight units ni of 4 (mi) MFMAs; stages rotate as uniform byte offsets
+    unsigned so = 0, no = STAGE, n2 = 2 * STAGE, po = 3 * STAGE;        // tile s, s+1, s+2, and the stage tile s+3 goes to
+    int bctr = gs0 % a.tiles_ci;
+    // af[0] holds this step's dz fragments, af[1] receives the next step's (the roles swap every step: two unrolled bodies)
+    auto body = [&](auto CUR_) {
+        constexpr int CUR = decltype(CUR_)::value, NXT = CUR ^ 1;
+        const char* Sb = smem + so;
+        const char* Nb = smem + no;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (u == 5) {
+                // tile s+1 has landed (this wave's pieces; the barrier covers the others'), every wave is past tile s-1
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                WIDE2_ISSUE(po);                                        // tile s + 3
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const u32x4 b = bf[u & 1];
+            if (u < 7) bf[(u + 1) & 1] = rdB(Sb, u + 1);
+            else bf[0] = rdB(Nb, 0);
+            if (u == 5) { af[NXT][0] = rdA(Nb, 0); af[NXT][1] = rdA(Nb, 1); }
+            if (u == 6) { af[NXT][2] = rdA(Nb, 2); af[NXT][3] = rdA(Nb, 3); }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) mma(b, af[CUR][mi], acc[mi][u]);
+            if (u == 5 || u == 6) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        if (do_bias && bctr == tile_ci) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (wn == 0) { mma(ones, af[CUR][0], bacc[0]); mma(ones, af[CUR][1], bacc[1]); }
+            else { mma(ones, af[CUR][2], bacc[0]); mma(ones, af[CUR][3], bacc[1]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (++bctr == a.tiles_ci) bctr = 0;
+        { const unsigned t4 = so; so = no; no = n2; n2 = po; po = t4; }
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        body(IC2<0>{});
+        if (s + 1 < nsteps) body(IC2<1>{});
+    }
+#undef WIDE2_ISSUE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the over-run tiles land before the workgroup ends
+    {
+        // slab = register dump [split][tile][wave][mi * 8 + ni][lane][4 ci]: 1-KiB store instructions (wgrad_reduce_wide2_kernel)
+        float* P = a.partial + (((long long)split * (a.tiles_co * a.tiles_ci) + t) * 8 + wave) * (32 * 256) + lane * 4;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+                *(f32x4*)(P + (mi * 8 + ni) * 256) = acc[mi][ni];
+    }
+    if (do_bias && lane < 16) {
+        float* bpt = a.bpartial + ((long long)split * a.tiles_ci + tile_ci) * a.co_pad + tile_co * 256 + wm * 64 + wn * 32 + lane;
+        bpt[0] = bacc[0].x; bpt[16] = bacc[1].x;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ 3x3, all taps per workgroup
 // For layers with few channels (Cout, Cin <= 128 at 240x240 / 120x120) the per-tap tiling above is bound by refilling
 // LDS: every tap re-reads the same dz rows and a shifted copy of the same x rows (32 FLOP per byte filled).  Here one
@@ -1228,7 +1396,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_c8_kernel(const WgradArgs a) {
 // with independent loads in flight and are combined in a fixed order through LDS, so results are bitwise repeatable.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits, int bsplits,
                                                            int co, int ci, int taps, int co_pad, int ci_pad, float* __restrict__ dw,
-                                                           float* __restrict__ db, int accumulate) {
+                                                           float* __restrict__ db, int accumulate, int ci_total, int ci_off) {
     const int c4n = ci_pad >> 2;                                       // 4-float groups per (co, tap) row
     const long long total4 = (long long)co * taps * c4n;
     const long long nb = (co + 3) / 4;                                 // bias groups (four couts each)
@@ -1270,7 +1438,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (c + j < ci) {
-                        float* out = dw + ((long long)o * ci + c + j) * taps + t;
+                        float* out = dw + ((long long)o * ci_total + ci_off + c + j) * taps + t;
                         *out = accumulate ? *out + vv[j] : vv[j];
                     }
             } else {
@@ -1287,11 +1455,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // consecutive 16-byte elements of a slab (one fragment of one wave), its four waves sum every fourth split with coalesced 1-KiB
 // loads and are combined in a fixed order through LDS (bitwise repeatable); element -> (co, tap, ci .. ci+3) -> fp32 OIHW.
 // Bias: bpartial [bsplits][co_pad], summed the same way by the workgroups past the last slab element.
+// WIDE: wgrad_wide2_kernel's dumps instead ([split][tile][wave][mi * 8 + ni][lane][4], 256 x 256 tiles, one tap).
+template <bool WIDE>
 __global__ __launch_bounds__(256) void wgrad_reduce_all9_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int splits,
                                                                 int bsplits, int co, int ci, int tiles_co, int tiles_ci, int co_pad,
-                                                                float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+                                                                float* __restrict__ dw, float* __restrict__ db, int accumulate, int ci_total, int ci_off) {
+    constexpr int NF = WIDE ? 32 : 36;
     const int ntile = tiles_co * tiles_ci;
-    const long long total4 = (long long)ntile * 8 * 36 * 64;            // 16-byte elements per slab
+    const long long total4 = (long long)ntile * 8 * NF * 64;            // 16-byte elements per slab
     const long long nb = (co + 3) / 4;
     const long long slab4 = total4;
     const int g = threadIdx.x >> 6, e = threadIdx.x & 63;
@@ -1324,17 +1495,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all9_kernel(const float* __r
             if (is_w) {
                 const int lane = (int)(i & 63);
                 long long r = i >> 6;
-                const int f = (int)(r % 36); r /= 36;
+                const int f = (int)(r % NF); r /= NF;
                 const int wave = (int)(r & 7); r >>= 3;
                 const int tile = (int)r, tile_ci = tile % tiles_ci, tile_co = tile / tiles_ci;
-                const int tp = f >> 2, mi = f & 3;
-                const int o = tile_co * 128 + (wave >> 2) * 64 + mi * 16 + (lane & 15);
-                const int c = tile_ci * 64 + (wave & 3) * 16 + (lane >> 4) * 4;
+                const int tp = WIDE ? 0 : f >> 2, mi = WIDE ? f >> 3 : f & 3, taps = WIDE ? 1 : 9;
+                const int o = WIDE ? tile_co * 256 + (wave >> 1) * 64 + mi * 16 + (lane & 15) : tile_co * 128 + (wave >> 2) * 64 + mi * 16 + (lane & 15);
+                const int c = WIDE ? tile_ci * 256 + (wave & 1) * 128 + (f & 7) * 16 + (lane >> 4) * 4 : tile_ci * 64 + (wave & 3) * 16 + (lane >> 4) * 4;
                 if (o < co) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (c + j < ci) {
-                            float* out = dw + ((long long)o * ci + c + j) * 9 + tp;
+                            float* out = dw + ((long long)o * ci_total + ci_off + c + j) * taps + tp;
                             *out = accumulate ? *out + vv[j] : vv[j];
                         }
                 }
@@ -1350,7 +1521,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_all9_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------ host
-struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3, wide, all9, bsplits; long long Q;
+struct WgradPlan { int bmc, bnc, co_pad, ci_pad, tiles_co, tiles_ci, taps, splits, rows_per_split, alltaps, c8, row3, wide, all9, wide2, bsplits; long long Q;
                    int strip, nstrips, units, units_per_split, spi, steps_total, steps_per_split; };
 
 static int device_cus() {            // CUs of the current device (workgroup targets of the one-round kernels)
@@ -1436,6 +1607,24 @@ static WgradPlan wgrad_plan(int dtype, const dbx_view* dz, const dbx_view* x, in
         p.rows_per_split = (int)(sps * 64);
         p.bsplits = p.splits * p.tiles_ci;
     }
+    p.wide2 = 0;
+    // wide 1x1 layers, round 3: the same pipeline on 256 x 256 tiles (DBX_WGRAD_VARIANT=20: wgrad_wide_kernel)
+    if (p.wide && wgrad_variant() == 0) {
+        p.wide2 = 1; p.all9 = 1; p.wide = 0;                                          // (all9: shares the one-round split rule and the dump reduce)
+        const int ntile = p.tiles_co * p.tiles_ci;
+        const bool compact = dz->pad >= 1 && (dz->w + 2 * dz->pad) >= 32;
+        p.spi = compact ? (dz->h * (dz->w + 2 * dz->pad) + 31) / 32 : 0;
+        const long long steps_tot = compact ? (long long)dz->n * p.spi : (p.Q + 31) / 32;
+        long long sp = device_cus() / ntile; if (sp < 1) sp = 1;
+        if (sp > steps_tot / 8) sp = steps_tot / 8 > 0 ? steps_tot / 8 : 1;
+        if (sp >= 8) sp = sp / 8 * 8;
+        const long long sps = (steps_tot + sp - 1) / sp;
+        p.splits = (int)((steps_tot + sps - 1) / sps);
+        if (sp >= 8 && p.splits % 8) p.splits = (int)sp;
+        p.steps_total = compact ? (int)steps_tot : 0; p.steps_per_split = compact ? (int)sps : 0;
+        p.rows_per_split = (int)(sps * 32);
+        p.bsplits = p.splits * p.tiles_ci;
+    }
     p.strip = (p.alltaps && !p.c8 && dz->w + 2 * dz->pad >= 64 && wgrad_variant() != 11) ? 1 : 0;
     p.nstrips = p.units = p.units_per_split = 0;
     if (p.strip) {
@@ -1464,7 +1653,8 @@ extern "C" int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_
     if (dtype != DBX_F16 && dtype != DBX_BF16 && dtype != DBX_F32) { dbx_set_error("bad dtype %d", (int)dtype); return DBX_ERR_DTYPE; }
     const WgradPlan p = wgrad_plan(dtype, dz, x, kh, kw);
     const char* tn = dtype == DBX_F32 ? "f32" : (dtype == DBX_F16 ? "f16" : "bf16");
-    if (p.all9) snprintf(name, name_len, "wgrad_all9_kernel<%s>", tn);
+    if (p.wide2) snprintf(name, name_len, "wgrad_wide2_kernel<%s>", tn);
+    else if (p.all9) snprintf(name, name_len, "wgrad_all9_kernel<%s>", tn);
     else if (p.c8) snprintf(name, name_len, "wgrad3x3_c8_kernel<%s>", tn);
     else if (p.alltaps && p.strip) snprintf(name, name_len, "wgrad3x3_strip_kernel<%s>", tn);
     else if (p.alltaps) snprintf(name, name_len, "wgrad3x3_kernel<%s>", tn);
@@ -1477,7 +1667,8 @@ extern "C" int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_
 
 template <typename T>
 static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cpad, int co, int ci, float* dw, float* db,
-                   void* scratch, int accumulate, hipStream_t s) {
+                   void* scratch, int accumulate, hipStream_t s, int ci_total, int ci_off) {
+    DBX_REQUIRE(ci_off >= 0 && ci_off + ci <= ci_total, "wgrad: column slice [%d, %d) outside the %d input channels of dw", ci_off, ci_off + ci, ci_total);
     constexpr int ES = sizeof(T);
     DBX_REQUIRE(dz->n == x->n && dz->h + 2 * dz->pad == x->h + 2 * x->pad && dz->w + 2 * dz->pad == x->w + 2 * x->pad,
                 "wgrad: dz frame %dx%d(+%d) and x frame %dx%d(+%d) are not congruent", dz->h, dz->w, dz->pad, x->h, x->w, x->pad);
@@ -1499,7 +1690,17 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.hp = a.nstrips = a.units = a.units_per_split = 0;
     a.spi = p.spi; a.img_rows = (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad); a.row0 = (dz->w + 2 * dz->pad) * dz->pad;
     a.steps_total = p.steps_total; a.steps_per_split = p.steps_per_split;
-    if (p.all9) {
+    if (p.wide2) {
+        if constexpr (sizeof(T) == 2) {
+            constexpr int smem = 4 * 2 * 32 * 512;
+            static bool attr_set = false;
+            if (!attr_set) {
+                DBX_HIP(hipFuncSetAttribute((const void*)wgrad_wide2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((wgrad_wide2_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a);
+        }
+    } else if (p.all9) {
         if constexpr (sizeof(T) == 2) {
             constexpr int smem = 3 * (64 * 256 + 3 * 72 * 128);
             static bool attr_set = false;
@@ -1558,17 +1759,21 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     }
     DBX_LAUNCH_CHECK();
     if (p.all9) {
-        const long long total = (long long)p.tiles_co * p.tiles_ci * 8 * 36 * 64 + (co + 3) / 4;
+        const long long total = (long long)p.tiles_co * p.tiles_ci * 8 * (p.wide2 ? 32 : 36) * 64 + (co + 3) / 4;
         int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
-        hipLaunchKernelGGL(wgrad_reduce_all9_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, p.bsplits, co, ci, p.tiles_co,
-                           p.tiles_ci, p.co_pad, dw, db, accumulate);
+        if (p.wide2)
+            hipLaunchKernelGGL(wgrad_reduce_all9_kernel<true>, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, p.bsplits, co, ci, p.tiles_co,
+                               p.tiles_ci, p.co_pad, dw, db, accumulate, ci_total, ci_off);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_all9_kernel<false>, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, p.bsplits, co, ci, p.tiles_co,
+                               p.tiles_ci, p.co_pad, dw, db, accumulate, ci_total, ci_off);
         DBX_LAUNCH_CHECK();
         return DBX_OK;
     }
     const long long total = (long long)co * p.taps * (p.ci_pad / 4) + (co + 3) / 4;
     int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, a.partial, a.bpartial, p.splits, p.bsplits, co, ci, p.taps, p.co_pad,
-                       p.ci_pad, dw, db, accumulate);
+                       p.ci_pad, dw, db, accumulate, ci_total, ci_off);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }
@@ -1578,7 +1783,7 @@ int dbx_internal_wgrad_reduce(const float* partial, const float* bpartial, int s
                               float* dw, float* db, int accumulate, hipStream_t s) {
     const long long total = (long long)co * taps * (ci_pad / 4) + (co + 3) / 4;
     int blocks = (int)((total + 63) / 64); blocks = blocks > 8192 ? 8192 : blocks;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, bpartial, splits, splits, co, ci, taps, co_pad, ci_pad, dw, db, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, bpartial, splits, splits, co, ci, taps, co_pad, ci_pad, dw, db, accumulate, ci, 0);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }
@@ -1586,5 +1791,11 @@ int dbx_internal_wgrad_reduce(const float* partial, const float* bpartial, int s
 extern "C" int dbx_conv_wgrad(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, int32_t cpad,
                               int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch, int32_t accumulate, void* stream) {
     if (!dz || !x || !dw_oihw || !scratch) { dbx_set_error("wgrad: null argument"); return DBX_ERR_ARG; }
-    DBX_DISPATCH_DTYPE(dtype, wgrad_t, dz, x, kh, kw, cpad, co, ci, dw_oihw, db, scratch, accumulate, (hipStream_t)stream);
+    DBX_DISPATCH_DTYPE(dtype, wgrad_t, dz, x, kh, kw, cpad, co, ci, dw_oihw, db, scratch, accumulate, (hipStream_t)stream, ci, 0);
+}
+extern "C" int dbx_conv_wgrad_slice(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, int32_t cpad,
+                                    int32_t co, int32_t ci, float* dw_oihw, int32_t dw_ci_total, int32_t dw_ci_off, float* db, void* scratch,
+                                    int32_t accumulate, void* stream) {
+    if (!dz || !x || !dw_oihw || !scratch) { dbx_set_error("wgrad: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(dtype, wgrad_t, dz, x, kh, kw, cpad, co, ci, dw_oihw, db, scratch, accumulate, (hipStream_t)stream, dw_ci_total, dw_ci_off);
 }

@@ -102,6 +102,7 @@ class Plan:
             add('d_ups', h4, w4, 512, pad=0)
             add('d_p1', h2, w2, 64, pad=0); add('d_p2', h4, w4, 128, pad=0); add('d_p3', h8, w8, 256, pad=0)
             add('d_hid', h4, w4, 512 * nh, pad=1)         # congruent with 'fusion'
+            add('d_g44', h8, w8, 512 * nh, pad=1)         # up^T(d_hid): the hidden gradient on conv4_4's grid, congruent with 'a44'
             add('d_out', h4, w4, self.crf * nh, pad=0)    # dL/d(head outputs), one crf-channel slot per head
             if kind != 'DenseBox':
                 add('d_rfo', h4, w4, self.crf, pad=0)
@@ -175,6 +176,7 @@ class Engine:
         return t
 
     def _pack(self, dt, mode, w, rows_pad, cin_pad, kh, kw, out=None, row_off=0, k_off=0):
+        # (row_off / k_off may be negative: elements that land outside [0, rows_pad) x [0, cin_pad) are skipped -- channel slices)
         """fp32 OIHW parameter -> packed compute-dtype matrix [rows_pad][ktot]."""
         d = ConvDesc(dt, kh, kw, 0, cin_pad, rows_pad, 0, 0)
         elems = self.L.dbx_conv_packed_elems(C.byref(d))
@@ -185,7 +187,7 @@ class Engine:
             es = _lib.ESIZE[dt]
             ktot = (kh * kw * cin_pad * es + 127) // 128 * 128 // es
             self._defer.append((w.data_ptr(), out.data_ptr(), co, ci, kh * kw, mode, rows_pad if mode >= 4 else ktot, cin_pad,
-                                row_off, k_off))
+                                row_off, k_off, rows_pad))
             self._defer_keep.append(out)
             return out
         check(self.L.dbx_pack_weight(dt, mode, ptr(w.detach()), co, ci, kh, kw, ptr(out), rows_pad, cin_pad,
@@ -203,7 +205,7 @@ class Engine:
         o = 0
         for p in ps:
             if self._defer is not None:
-                self._defer.append((p.data_ptr(), b.data_ptr(), p.numel(), 1, 1, 2, 0, 0, o, 0))
+                self._defer.append((p.data_ptr(), b.data_ptr(), p.numel(), 1, 1, 2, 0, 0, o, 0, 0))
             else:
                 b[o:o + p.numel()].copy_(p.detach())
             o += p.numel()
@@ -252,6 +254,12 @@ class Engine:
             B, nh = P.B, len(_HEADS[self.kind])
             if which == 'f':
                 r = self.conv_plan(dt, B['fusion'].view(), B['hid'].view(), 1, 1, 0, 768, 512 * nh, _lib.EPI_BIAS | _lib.EPI_DROPHASH)[2]
+            elif which == 'ba' and 'd_g44' in B and dt != _lib.F32:
+                r = self.conv_plan(dt, B['d_g44'].view(), B['d_a44'].view(), 1, 1, 0, 512 * nh, 512, _lib.EPI_GATE)[2]
+            elif which == 'bc' and 'd_hid' in B and dt != _lib.F32:
+                r = self.conv_plan(dt, B['d_hid'].view(), B['d_c34'].view(), 1, 1, 0, 512 * nh, 256, _lib.EPI_GATE)[2]
+            elif which in ('ba', 'bc'):
+                r = False
             elif 'd_hid' in B and dt != _lib.F32:
                 dv = B['d_ups'].view()
                 both = View(dv.ptr, dv.n, dv.h, dv.w, dv.pad, 768, 0, 768)      # both destinations' couts, for planning only
@@ -281,7 +289,11 @@ class Engine:
         if train:
             for stem, cin, cout in _BACKBONE[1:]:
                 self._w_bwd(dt, stem, max(64, cin), cout, frag=self._frag(P, dt, stem, 'b'))
-            self._w_heads1_bwd(dt, frag=self._frag_heads(P, dt, 'b'))
+            if self._lin_bwd(dt):
+                self._w_heads1_bwd_part(dt, 'a', frag=self._frag_heads(P, dt, 'ba'))
+                self._w_heads1_bwd_part(dt, 'c', frag=self._frag_heads(P, dt, 'bc'))
+            else:
+                self._w_heads1_bwd(dt, frag=self._frag_heads(P, dt, 'b'))
             if kind != 'DenseBox':
                 self._w_bwd(dt, 'conv6_3_det', 64, P.crf)
                 self._w_bwd(dt, 'conv6_2_det', 64, 64)
@@ -292,7 +304,8 @@ class Engine:
         params = [p for _, p in self.net.named_parameters()]
         lay = tuple(self._frag(P, dt, st, wh) for st, _, _ in _BACKBONE for wh in ('f', 'b'))   # layouts the kernels of this plan want
         if train:
-            lay += (self._frag_heads(P, dt, 'f'), self._frag_heads(P, dt, 'b'))
+            lay += (self._frag_heads(P, dt, 'f'),) + ((self._frag_heads(P, dt, 'ba'), self._frag_heads(P, dt, 'bc')) if self._lin_bwd(dt)
+                                                      else (self._frag_heads(P, dt, 'b'),))
         sig = (dt, train, tuple((p._version, p.data_ptr()) for p in params), lay)
         if sig == self._wsig:
             return
@@ -307,9 +320,9 @@ class Engine:
             self._table_keys = set(self.wcache) | set(self.bias_cache)
             rec = np.zeros(len(jobs), dtype=[('src', '<u8'), ('dst', '<u8'), ('co', '<i4'), ('ci', '<i4'), ('taps', '<i4'),
                                              ('mode', '<i4'), ('ktot', '<i8'), ('cin_pad', '<i4'), ('row_off', '<i4'),
-                                             ('k_off', '<i4'), ('_pad', '<i4')])
+                                             ('k_off', '<i4'), ('rows_lim', '<i4')])
             for i, j in enumerate(jobs):
-                rec[i] = j + (0,)
+                rec[i] = j
             dev = params[0].device
             tab = (torch.from_numpy(rec.view(np.uint8).copy()).to(dev), len(jobs), max(j[2] * j[3] * j[4] for j in jobs))
             self._tables = {tkey: tab}
@@ -601,7 +614,27 @@ class Engine:
             return out
         return self._packed(('heads1', mode, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
 
-    def _wgrad(self, dt, dz, x, kh, kw, cpad, co, ci, dw, db, accumulate=0):
+    def _w_heads1_bwd_part(self, dt, part, frag=False):
+        """dgrad weights of one part of the fusion concat: rows = that part's input channels (part 'a': 0..511, the up-sampled
+        conv4_4; 'c': 512..767, conv3_4), K = the 512 nh hidden channels of all heads."""
+        heads = _HEADS[self.kind]
+        ws = [self._param('conv5_1_%s.weight' % s) for s, _ in heads]
+        mode = 5 if frag else 1
+        rows, roff = (512, 0) if part == 'a' else (256, -512)
+
+        def build(out):
+            for i, w in enumerate(ws):
+                out = self._pack(dt, mode, w, rows, 512 * len(ws), 1, 1, out=out, row_off=roff, k_off=512 * i)
+            return out
+        return self._packed(('heads1_' + part, mode, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+
+    def _lin_bwd(self, dt):
+        """Heads backward by linearity of the bilinear up-sampling (16-bit types): W [up(a44); c34] = up(W_a a44) + W_c c34, so the
+        conv4_4 part of the 768 -> 512 nh GEMM's data and weight gradients runs on conv4_4's 30x30 grid (a quarter of the pixels)
+        after ONE transposed up-sampling of the hidden gradient.  DBX_LIN_BWD=0 keeps the full-resolution GEMMs."""
+        return dt != _lib.F32 and os.environ.get('DBX_LIN_BWD', '1') != '0'
+
+    def _wgrad(self, dt, dz, x, kh, kw, cpad, co, ci, dw, db, accumulate=0, ci_total=None, ci_off=0):
         need = self.L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dz), C.byref(x), kh, kw)
         if getattr(self, '_wg_scratch', None) is None or self._wg_scratch.numel() < need:
             self._wg_scratch = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=dw.device)
@@ -609,8 +642,12 @@ class Engine:
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        check(self.L.dbx_conv_wgrad(dt, C.byref(dz), C.byref(x), kh, kw, cpad, co, ci, ptr(dw), ptr(db),
-                                    ptr(self._wg_scratch), accumulate, stream_ptr()))
+        if ci_total is None:
+            check(self.L.dbx_conv_wgrad(dt, C.byref(dz), C.byref(x), kh, kw, cpad, co, ci, ptr(dw), ptr(db),
+                                        ptr(self._wg_scratch), accumulate, stream_ptr()))
+        else:
+            check(self.L.dbx_conv_wgrad_slice(dt, C.byref(dz), C.byref(x), kh, kw, cpad, co, ci, ptr(dw), ci_total, ci_off, ptr(db),
+                                              ptr(self._wg_scratch), accumulate, stream_ptr()))
         if prof is not None:
             ev1.record()
             buf = C.create_string_buffer(64)                      # the library's own choice (dbx_conv_wgrad_plan)
@@ -752,19 +789,35 @@ class Engine:
         else:
             dw1 = torch.empty((512 * nh, 768, 1, 1), dtype=torch.float32, device=dev)
             db1 = torch.empty((512 * nh,), dtype=torch.float32, device=dev)
+        c34 = B['fusion'].view(512, 256)
+        lin = self._lin_bwd(dt)
+        if lin:
+            # the hidden gradient on conv4_4's grid: d_g44 = up^T(d_hid) (one HBM-bound pass over the 2048-channel map)
+            check(L.dbx_upsample_bilinear_bwd(dt, C.byref(B['d_hid'].view()), C.byref(B['d_g44'].view()), None, s))
+
         def run_h1():
-            self._wgrad(dt, B['d_hid'].view(), B['fusion'].view(), 1, 1, 0, 512 * nh, 768, dw1, db1)
+            if lin:       # columns 0..511 of dW1 from (d_g44, a44) at 30x30, columns 512..767 (+ the bias) from (d_hid, c34) at 60x60
+                self._wgrad(dt, B['d_g44'].view(), B['a44'].view(), 1, 1, 0, 512 * nh, 512, dw1, None, ci_total=768, ci_off=0)
+                self._wgrad(dt, B['d_hid'].view(), c34, 1, 1, 0, 512 * nh, 256, dw1, db1, ci_total=768, ci_off=512)
+            else:
+                self._wgrad(dt, B['d_hid'].view(), B['fusion'].view(), 1, 1, 0, 512 * nh, 768, dw1, db1)
             if sink is not None:
                 sink.ready(w1n + b1n)
         on_side(run_h1)
         for i, (stem, _) in enumerate(heads):
             G['conv5_1_%s.weight' % stem] = dw1[512 * i:512 * (i + 1)]
             G['conv5_1_%s.bias' % stem] = db1[512 * i:512 * (i + 1)]
-        bfrag = dt != _lib.F32 and self._frag_heads(P, dt, 'b')
-        w1t = self._w_heads1_bwd(dt, frag=bfrag)              # [768 rows][512*nh] (or its fragment-order image)
         row_bytes = 512 * nh * _lib.ESIZE[dt]
-        c34 = B['fusion'].view(512, 256)
-        if dt != _lib.F32:
+        if lin:
+            # data gradients of the two concat parts: d_a44 = gate(W_a^T d_g44) at 30x30, d_c34 = gate(W_c^T d_hid) at 60x60
+            fa, fc = self._frag_heads(P, dt, 'ba'), self._frag_heads(P, dt, 'bc')
+            self._conv(dt, B['d_g44'].view(), B['d_a44'].view(), self._w_heads1_bwd_part(dt, 'a', frag=fa), None, 1, 1, 0, 512 * nh, 512,
+                       _lib.EPI_GATE | (_lib.CONV_WFRAG if fa else 0), gate=B['a44'].view())
+            self._conv(dt, B['d_hid'].view(), B['d_c34'].view(), self._w_heads1_bwd_part(dt, 'c', frag=fc), None, 1, 1, 0, 512 * nh, 256,
+                       _lib.EPI_GATE | (_lib.CONV_WFRAG if fc else 0), gate=c34)
+        elif dt != _lib.F32:
+            bfrag = self._frag_heads(P, dt, 'b')
+            w1t = self._w_heads1_bwd(dt, frag=bfrag)              # [768 rows][512*nh] (or its fragment-order image)
             # one pass over d_hid for both branches of the concat: couts 0..511 -> d_ups, 512..767 -> d_c34 (ReLU-gated)
             d = ConvDesc(dt, 1, 1, 0, 512 * nh, 768, _lib.CONV_WFRAG if bfrag else 0, 0)
             prof = self.profile
@@ -782,11 +835,13 @@ class Engine:
                              'conv_igemm_dma_kernel<%s,256,256>' % ('f16', 'bf16', 'f32')[dt],
                              'flops': 2.0 * hv.n * hv.h * hv.w * 512 * nh * 768, 'start': ev0, 'end': ev1})
         else:
+            w1t = self._w_heads1_bwd(dt, frag=False)
             self._conv(dt, B['d_hid'].view(), B['d_ups'].view(), w1t, None, 1, 1, 0, 512 * nh, 512, 0)
             self._conv(dt, B['d_hid'].view(), B['d_c34'].view(), w1t[512 * row_bytes:], None, 1, 1, 0, 512 * nh, 256,
                        _lib.EPI_GATE, gate=c34)
-        check(L.dbx_upsample_bilinear_bwd(dt, C.byref(B['d_ups'].view()), C.byref(B['d_a44'].view()),
-                                          C.byref(B['a44'].view()), s))
+        if not lin:
+            check(L.dbx_upsample_bilinear_bwd(dt, C.byref(B['d_ups'].view()), C.byref(B['d_a44'].view()),
+                                              C.byref(B['a44'].view()), s))
 
         # ---- backbone, deepest first.  (stem, dz, x, cin, cout, where the data gradient goes, its ReLU gate)
         chain = [

@@ -121,14 +121,17 @@ int dbx_conv_forward_pool(const dbx_conv_desc* d, const dbx_view* x, const void*
  *   [row / BN][3 * (k / 64) + ky][kx * 4 + (k % 64) / 16][(row % BN) / 32][32 * ((k % 16) / 8) + row % 32][k % 8],
  *   BN = 256 if rows_pad % 256 == 0 else 128, KC = cin_pad / 64 -- one 1-KiB block is the A operand of one
  *   v_mfma_f32_32x32x16 for all 64 lanes.  Same size as modes 0 / 1.
- * ci_off/ci_cnt select an input-channel slice (used to concatenate several heads' 1x1 weights). */
+ * row_off / k_off place the tensor inside a larger packed matrix (several heads' 1x1 weights side by side); elements whose
+ * destination row / column falls outside [0, rows_pad) x [0, cin_pad) are skipped, so a NEGATIVE offset packs a channel range of
+ * a wider tensor (the conv4_4 / conv3_4 parts of the 768-channel head weights). */
 int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw, int32_t co, int32_t ci, int32_t kh, int32_t kw,
                     void* w_packed, int32_t rows_pad, int32_t cin_pad, int32_t row_off, int32_t k_off, void* stream);
 
 /* All parameters in ONE launch (after an optimizer step).  `jobs` is a device array of
  *   struct { const float* src; void* dst; int32 co, ci, taps, mode; int64 ktot; int32 cin_pad, row_off, k_off; }
- * mode 0/1/4/5 as dbx_pack_weight (4/5: ktot carries rows_pad), mode 2 = fp32 bias copy into dst[row_off ...]
- * (co = length, ci = taps = 1). */
+ * followed by int32 rows_lim (rows of dst for modes 0/1, 0 = unchecked; the record is 56 bytes).
+ * mode 0/1/4/5 as dbx_pack_weight (4/5: ktot carries rows_pad; out-of-range destinations are skipped), mode 2 = fp32 bias copy
+ * into dst[row_off ...] (co = length, ci = taps = 1). */
 int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, void* stream);
 
 /* heads: data gradient of the nh (<= 4) Conv1x1(512->k_h) layers behind Dropout in one rank-k streaming pass:
@@ -166,6 +169,12 @@ int64_t dbx_conv_wgrad_scratch_bytes(int32_t dtype, const dbx_view* dz, const db
  * db may be NULL.  accumulate != 0 adds into dw/db instead of overwriting. */
 int dbx_conv_wgrad(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, int32_t cpad,
                    int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch, int32_t accumulate, void* stream);
+/* The same with dw a column slice of a wider tensor: dw_oihw is [co][dw_ci_total][kh][kw] and the ci input channels of x go to
+ * columns [dw_ci_off, dw_ci_off + ci) -- the gradient of a convolution over a channel concat (torch.cat, DenseBox.py:219),
+ * computed per concatenated tensor (the two may then live on different grids: see dbx_upsample_bilinear_bwd). */
+int dbx_conv_wgrad_slice(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, int32_t cpad,
+                         int32_t co, int32_t ci, float* dw_oihw, int32_t dw_ci_total, int32_t dw_ci_off, float* db, void* scratch,
+                         int32_t accumulate, void* stream);
 /* The kernel dbx_conv_wgrad runs for this problem ("wgrad_row3_kernel<bf16>" ...) and its split-K factor: the library's own
  * selection, for profile labels (no caller-side copy of the rule).  name_len >= 32. */
 int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw, char* name, int32_t name_len,

@@ -80,6 +80,8 @@ WG_CASES = [  # n, h, w, cin (view), cin real, cout, k, pad
     (3, 41, 77, 64, 64, 64, 3, 1), (2, 30, 126, 64, 64, 128, 3, 1), (5, 20, 62, 128, 100, 64, 3, 1),      # column-strip walk: ragged last strip
     # all-nine-taps LDS-DMA ring kernel (wgrad_all9_kernel): image seams of the compact walk, several splits and ci tiles
     (5, 30, 30, 512, 512, 512, 3, 1), (3, 60, 60, 128, 128, 256, 3, 1), (2, 120, 120, 64, 64, 128, 3, 1), (7, 30, 33, 192, 192, 128, 3, 1),
+    # wide 1x1 LDS-DMA ring kernel (wgrad_wide2_kernel): compact walk with image seams, two ci tiles / one ci tile
+    (5, 30, 30, 512, 512, 1024, 1, 0), (2, 60, 60, 256, 256, 512, 1, 0),
 ]
 
 
@@ -525,7 +527,8 @@ def test_conv_dgrad_wgrad1_equals_dgrad_then_wgrad(shape, dtn):
 
 
 @pytest.mark.parametrize('dtn', ['bf16', 'f16', 'f32'])
-@pytest.mark.parametrize('shape', [(3, 64, 15, 15, 30, 30), (2, 40, 12, 16, 25, 33), (2, 512, 30, 30, 60, 60), (1, 8, 7, 9, 7, 9)])
+@pytest.mark.parametrize('shape', [(3, 64, 15, 15, 30, 30), (2, 40, 12, 16, 25, 33), (2, 512, 30, 30, 60, 60), (1, 8, 7, 9, 7, 9),
+                                   (1, 2048, 30, 30, 60, 60), (2, 1024, 15, 17, 29, 33)])      # column-walk kernel: wide maps, odd row count
 def test_upsample_bilinear_forward_backward(shape, dtn):
     """dbx_upsample_bilinear(_bwd) == F.interpolate(mode='bilinear', align_corners=True) and its autograd transpose (with the
     optional ReLU gate), on the 2x case, the odd-size case of a 100x132 input and the identity."""
