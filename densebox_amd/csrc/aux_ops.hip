@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_rows_kernel(FrameGeo dy, Fra
 // x0 and x0 + 1 it interpolates from); an accumulator is stored when the walk leaves its column.  Same coefficients as the
 // forward (bilin_coef), fp32 accumulation, y before x.
 template <typename T>
-__global__ __launch_bounds__(256) void upsample_bwd_walk_kernel(FrameGeo dy, FrameGeo dx, FrameGeo gate, int has_gate, float sy, float sx, int pairs) {
+__global__ __launch_bounds__(256, 4) void upsample_bwd_walk_kernel(FrameGeo dy, FrameGeo dx, FrameGeo gate, int has_gate, float sy, float sx, int pairs, int nseg) {
     constexpr int V = Vec<T>::N, MAXR = 8;
     extern __shared__ __attribute__((aligned(16))) char up_smem[];
     int* s_x0 = (int*)up_smem;                          // [dy.w] first source column of destination column ox
@@ -430,11 +430,16 @@ __global__ __launch_bounds__(256) void upsample_bwd_walk_kernel(FrameGeo dy, Fra
     float* s_l1 = s_l0 + dy.w;                          // [dy.w] weight of source column x0 + 1 (0 when x1 == x0)
     __shared__ int s_oy[MAXR];
     __shared__ float s_w[2][MAXR];
-    __shared__ int s_ny;
-    // workgroup b runs on XCD b % 8: give every XCD a contiguous range of row pairs (neighbouring pairs share destination rows)
+    __shared__ int s_ny, s_oxr[2];
+    // workgroup b runs on XCD b % 8: give every XCD a contiguous range of row pairs (neighbouring pairs share destination rows).
+    // A row pair is cut into nseg segments of source columns, one workgroup each (more waves in flight: a thread's walk is a serial
+    // chain of ~60 load / accumulate rounds); a segment walks the destination columns that touch its source columns and drops what
+    // falls outside them.
     const int nwg = gridDim.x;
     int b = blockIdx.x;
     { const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, j = b >> 3; b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j; }
+    const int seg = b % nseg; b /= nseg;
+    const int c_lo = (int)((long long)dx.w * seg / nseg), c_hi = (int)((long long)dx.w * (seg + 1) / nseg);
     const int n = b / pairs, iy0 = 2 * (b - n * pairs);
     const bool two = iy0 + 1 < dx.h;
     if (threadIdx.x == 0) {
@@ -457,34 +462,56 @@ __global__ __launch_bounds__(256) void upsample_bwd_walk_kernel(FrameGeo dy, Fra
         s_x0[ox] = x0; s_l0[ox] = x1 == x0 ? lx0 + lx1 : lx0; s_l1[ox] = x1 == x0 ? 0.f : lx1;
     }
     __syncthreads();
-    const int ny = s_ny, cg = dx.c / V;
+    if (threadIdx.x == 0) {                                             // destination columns with x0 in [c_lo - 1, c_hi - 1]
+        int lo = dy.w, hi = -1;
+        for (int ox = 0; ox < dy.w; ++ox) { const int x0 = s_x0[ox]; if (x0 >= c_lo - 1 && x0 <= c_hi - 1) { if (ox < lo) lo = ox; hi = ox; } }
+        s_oxr[0] = lo; s_oxr[1] = hi;
+    }
+    __syncthreads();
+    const int ox_lo = __builtin_amdgcn_readfirstlane(s_oxr[0]), ox_hi = __builtin_amdgcn_readfirstlane(s_oxr[1]);
+    const int ny = __builtin_amdgcn_readfirstlane(s_ny), cg = dx.c / V;
     const int dys = (int)(geo_pix(dy, n, 0, 1) - geo_pix(dy, n, 0, 0)), dxs = (int)(geo_pix(dx, n, 0, 1) - geo_pix(dx, n, 0, 0));
-    for (int g = threadIdx.x; g < cg; g += 256) {
-        const T* rows[MAXR];
+    const int gts = (int)(geo_pix(gate, n, 0, 1) - geo_pix(gate, n, 0, 0));
+    // uniform element offsets of the destination rows (rows past ny repeat row 0 with weight 0: fixed trip count, no divergence)
+    // (read from LDS, i.e. into VGPRs: readfirstlane moves them to scalar registers -- 32 VGPRs, one wave per SIMD more)
+    unsigned rowoff[MAXR];
+    float wa[MAXR], wb[MAXR];
 #pragma unroll
-        for (int r = 0; r < MAXR; ++r) rows[r] = (const T*)dy.base + geo_pix(dy, n, s_oy[r < ny ? r : 0], 0) + g * V;
-        T* out0 = (T*)dx.base + geo_pix(dx, n, iy0, 0) + g * V;
-        T* out1 = (T*)dx.base + geo_pix(dx, n, two ? iy0 + 1 : iy0, 0) + g * V;
-        const T* gt0 = (const T*)gate.base + geo_pix(gate, n, iy0, 0) + g * V;
-        const T* gt1 = (const T*)gate.base + geo_pix(gate, n, two ? iy0 + 1 : iy0, 0) + g * V;
-        const int gts = (int)(geo_pix(gate, n, 0, 1) - geo_pix(gate, n, 0, 0));
+    for (int r = 0; r < MAXR; ++r) {
+        rowoff[r] = (unsigned)__builtin_amdgcn_readfirstlane((int)geo_pix(dy, n, s_oy[r < ny ? r : 0], 0));
+        wa[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r < ny ? s_w[0][r] : 0.f)));
+        wb[r] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, r < ny ? s_w[1][r] : 0.f)));
+    }
+    const size_t o0 = geo_pix(dx, n, iy0, 0), o1 = geo_pix(dx, n, two ? iy0 + 1 : iy0, 0);
+    const size_t g0 = geo_pix(gate, n, iy0, 0), g1 = geo_pix(gate, n, two ? iy0 + 1 : iy0, 0);
+    for (int g = threadIdx.x; g < cg; g += 256) {
+        const T* in = (const T*)dy.base + g * V;                        // + uniform offsets: one lane offset register
+        T* out = (T*)dx.base + g * V;
+        const T* gt = (const T*)gate.base + g * V;
         float c0[V], c1[V], n0[V], n1[V];
 #pragma unroll
         for (int j = 0; j < V; ++j) c0[j] = c1[j] = n0[j] = n1[j] = 0.f;
         auto flush = [&](int col, float (&a0)[V], float (&a1)[V]) {
+            if (col < c_lo || col >= c_hi) return;                      // (uniform) another segment's column
             if (has_gate) {
                 float ga[V], gb[V];
-                load_vec<T>(gt0 + (size_t)col * gts, ga); load_vec<T>(gt1 + (size_t)col * gts, gb);
+                load_vec<T>(gt + g0 + (size_t)col * gts, ga); load_vec<T>(gt + g1 + (size_t)col * gts, gb);
 #pragma unroll
                 for (int j = 0; j < V; ++j) { a0[j] = ga[j] > 0.f ? a0[j] : 0.f; a1[j] = gb[j] > 0.f ? a1[j] : 0.f; }
             }
-            store_vec<T>(out0 + (size_t)col * dxs, a0);
-            if (two) store_vec<T>(out1 + (size_t)col * dxs, a1);
+            store_vec<T>(out + o0 + (size_t)col * dxs, a0);
+            if (two) store_vec<T>(out + o1 + (size_t)col * dxs, a1);
         };
-        int cur = s_x0[0];
-        for (int ox = 0; ox < dy.w; ++ox) {
+        if (ox_hi < ox_lo) continue;
+        int cur = s_x0[ox_lo];
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
             const int x0 = s_x0[ox];
             const float l0 = s_l0[ox], l1 = s_l1[ox];
+            // all of the column's loads go out first (16 bytes each, raw), then one row at a time is converted and accumulated
+            u32x4 raw[MAXR];
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r)
+                if (r < ny) raw[r] = *(const u32x4*)(in + (rowoff[r] + (unsigned)(ox * dys)));
             if (x0 != cur) {                                          // (uniform) the walk left column `cur`
                 flush(cur, c0, c1);
 #pragma unroll
@@ -497,11 +524,9 @@ __global__ __launch_bounds__(256) void upsample_bwd_walk_kernel(FrameGeo dy, Fra
 #pragma unroll
             for (int r = 0; r < MAXR; ++r) {
                 if (r < ny) {
-                    float d[V];
-                    load_vec<T>(rows[r] + (size_t)ox * dys, d);
-                    const float wa = s_w[0][r], wb = s_w[1][r];
+                    const T* e = (const T*)&raw[r];
 #pragma unroll
-                    for (int j = 0; j < V; ++j) { v0[j] += wa * d[j]; v1[j] += wb * d[j]; }
+                    for (int j = 0; j < V; ++j) { const float d = to_f32(e[j]); v0[j] += wa[r] * d; v1[j] += wb[r] * d; }
                 }
             }
 #pragma unroll
@@ -528,8 +553,13 @@ static int upsample_bwd_t(const dbx_view* dy, const dbx_view* dx, const dbx_view
     const bool rows_ok = sy > 0.34f && sx > 0.34f && dx->w <= 1536;
     if (walk_ok) {
         const int pairs = (dx->h + 1) / 2;
-        hipLaunchKernelGGL(upsample_bwd_walk_kernel<T>, dim3(dx->n * pairs), dim3(256), (size_t)dy->w * 12, s, make_geo<T>(dy), make_geo<T>(dx), gg,
-                           gate ? 1 : 0, sy, sx, pairs);
+        // enough workgroups for ~12 waves per SIMD over the channel-group rounds of a thread (at most one segment per 8 source columns)
+        const int rounds = (dx->c / Vec<T>::N + 255) / 256;
+        int nseg = (int)(12288 / ((int64_t)dx->n * pairs * 4 * rounds) + 1);
+        if (nseg > dx->w / 8) nseg = dx->w / 8;
+        if (nseg < 1) nseg = 1;
+        hipLaunchKernelGGL(upsample_bwd_walk_kernel<T>, dim3(dx->n * pairs * nseg), dim3(256), (size_t)dy->w * 12, s, make_geo<T>(dy), make_geo<T>(dx), gg,
+                           gate ? 1 : 0, sy, sx, pairs, nseg);
     } else if (rows_ok)
         hipLaunchKernelGGL(upsample_bwd_rows_kernel<T>, dim3(dx->n * dx->h), dim3(256), (size_t)dx->w * (4 + 8 * 4), s, make_geo<T>(dy), make_geo<T>(dx), gg,
                            gate ? 1 : 0, sy, sx);
