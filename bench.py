@@ -35,6 +35,7 @@ FWD_GFLOP = {'DenseBox': 41.98, 'DenseBoxLM': 44.95, 'DenseBoxLMLOC': 47.81}
 STEP_GFLOP = {'DenseBox': 125.7, 'DenseBoxLM': 134.6, 'DenseBoxLMLOC': 143.2}
 MFMA_PEAK_TF = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}     # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+PMC_FILE = 'r03_pmc_traffic.json'
 
 
 def conv_flops(eng_calls):
@@ -76,9 +77,41 @@ def cpu_baseline(kind, seconds=20.0):
         el = time.perf_counter() - t0
         if el >= seconds or it >= 50:
             break
-    return {'value': round(n * it / el, 3), 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d training steps of %d synthetic 240x240 patches (%s, fp32, oracle/densebox_oracle.py), %.1f s'
-                      % (it, n, kind, el)}
+    out = {'value': round(n * it / el, 3), 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': '%d training steps of %d synthetic 240x240 patches (%s, fp32, oracle/densebox_oracle.py), %.1f s'
+                     % (it, n, kind, el)}
+    # BASELINE.md section 4, cases (i) and (iii): eval forward at N = 1 / 8 and the whole-image inference chain (forward + top-K
+    # decode + NMS) at 512x512 and 1920x1080, same oracle, bounded to a few seconds each
+    Pd = {k: v.detach() for k, v in P.items()}
+
+    def timed(fn, budget, max_it):
+        fn()
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            fn()
+            k += 1
+            e = time.perf_counter() - t0
+            if e >= budget or k >= max_it:
+                return e / k, k
+    cases = {}
+    with torch.no_grad():
+        for nn_ in (1, 8):
+            xf = synth.synth_batch(nn_, seed=5, neg_frac=0.0)[0]
+            sec, k = timed(lambda: O.forward('DenseBox', Pd, xf), 2.0, 10)
+            cases['forward_DenseBox_N%d_240x240' % nn_] = {'patches_per_s': round(nn_ / sec, 2), 'iterations': k}
+        for name, (h, w) in (('512x512', (512, 512)), ('1920x1080', (1080, 1920))):
+            img = synth.synth_images(1, h, w, seed=1)
+
+            def chain():
+                o = O.forward('DenseBox', Pd, img)
+                sc, lc = o[0], o[1]
+                dets = O.parse_det(sc[0, 0].numpy(), lc[0].numpy(), h, w, K=10)
+                O.nms(dets, 0.4)
+            sec, k = timed(chain, 4.0, 5)
+            cases['inference_DenseBox_%s' % name] = {'img_per_s': round(1.0 / sec, 3), 'iterations': k}
+    out['cases'] = cases
+    return out
 
 
 def csrc_hash():
@@ -93,31 +126,25 @@ def csrc_hash():
 
 
 def pmc_traffic(family):
-    """HBM bytes per launch of a kernel family from the committed PMC summary (profiles/r02_pmc_traffic.json: separate
+    """HBM bytes per launch of a kernel family from the committed PMC summary (profiles/r03_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH_SIZE doubled per the gfx950 correction
     in MI355X_MICROARCH.md; tools/pmc_traffic.py stamps it with csrc_hash()).  None when the summary is absent, was
-    collected on other kernel sources, or does not list the family."""
-    path = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+    collected on other kernel sources, does not list the family, or lists more than one symbol that fits it."""
+    path = os.path.join(ROOT, 'profiles', PMC_FILE)
     if not os.path.exists(path):
         return None
     doc = json.load(open(path))
     if doc.get('csrc_hash') != csrc_hash():
         return None
-    # rocprof names are mangled: match on the family name and its template integers
+    # the library names a family by its kernel template and the leading template arguments (dbx_conv_plan / dbx_conv_wgrad_plan);
+    # a mangled symbol carries them as one contiguous run: name I <type code> Li<int>E ... -- matched as that exact prefix
     m = re.match(r'(\w+)<(\w+)((?:,\d+)*)>', family)
     if not m:
         return None
     code = {'bf16': 'DF16b', 'f16': 'DF16_', 'f32': 'f'}[m.group(2)]
-    ints = [v for v in m.group(3).split(',') if v]
-    name, want = m.group(1), ['Li%sE' % i for i in ints[-1:]]
-    if name in ('conv3x3_ws_kernel', 'conv1x1_ws_kernel'):
-        # the plan names the ws kernels by tile (256x256 / 512x128); the symbol carries <T, wave rows, kernel size>
-        want = ['Li%dELi%dE' % (1 if ints[:1] == ['256'] else 2, 3 if name == 'conv3x3_ws_kernel' else 1)]
-        name = 'conv3x3_ws_kernel'
-    for k, v in doc.get('kernels', {}).items():
-        if name in k and ('I' + code) in k and all(w in k for w in want):
-            return round(v['hbm_bytes_per_launch'])
-    return None
+    want = '%sI%s%s' % (m.group(1), code, ''.join('Li%sE' % v for v in m.group(3).split(',') if v))
+    hits = [v for k, v in doc.get('kernels', {}).items() if want in k]
+    return round(hits[0]['hbm_bytes_per_launch']) if len(hits) == 1 else None
 
 
 def inference(kind, dev):
@@ -299,15 +326,18 @@ def main():
             return {'tflops': round(fl / (us * 1e-6) / 1e12, 1), 'frac': round(fl / (us * 1e-6) / 1e12 / peak, 4),
                     'us_per_step': round(us / 3, 1)} if us > 0 else None
         # the dominant forward / data-gradient conv family on its own (round 1's dominant kernel was one: continuity of the series)
-        convs = {k: v for k, v in fam.items() if k.startswith('conv3x3_') or k.startswith('conv1x1_')}
+        convs = {k: v for k, v in fam.items() if k.startswith('conv3x3_') and not re.match(r'conv3x3_ws_kernel<\w+,\d+,1,', k)}
         if convs:
             dc = max(convs, key=lambda k: convs[k]['us'])
             ac = convs[dc]['flops'] / (convs[dc]['us'] * 1e-6) / 1e12
             roof['dominant_conv'] = {'kernel': dc, 'achieved': round(ac, 1), 'frac': round(ac / peak, 4),
                                      'launches_per_step': convs[dc]['launches'] // 3, 'us_per_step': round(convs[dc]['us'] / 3, 1),
                                      'traffic': pmc_traffic(dc)}
-        roof['stack_3x3'] = {'fwd_dgrad': agg(lambda k: k.startswith('conv3x3_')),
-                             'with_wgrad': agg(lambda k: k.startswith('conv3x3_') or k.startswith('wgrad_row3') or k.startswith('wgrad3x3'))}
+        # (the ws kernel template serves 3x3 layers <T,WM,3,EPIK> and the 1x1 head GEMMs <T,1,1,EPIK>: only the former belong here)
+        def is3(k):
+            return k.startswith('conv3x3_') and not re.match(r'conv3x3_ws_kernel<\w+,\d+,1,', k)
+        roof['stack_3x3'] = {'fwd_dgrad': agg(is3),
+                             'with_wgrad': agg(lambda k: is3(k) or k.startswith(('wgrad_all9', 'wgrad_row3', 'wgrad3x3')))}
         out = {
             'metric': 'training patches/sec (240x240)', 'value': round(value, 1), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
@@ -318,11 +348,16 @@ def main():
                        'parallelism': 'dp%d' % world, 'half_neg': half, 'loss': round(loss_val, 2)},
             'step_tflops_per_gpu': round(n * STEP_GFLOP[kind] / (ms * 1e-3) / 1e3, 1),
             'roofline': roof,
+            # the live process group the gradient all-reduce ran on ("nccl" is RCCL on ROCm): lets a scaling run be checked for
+            # "RCCL saw N ranks"
+            'rccl': {'backend': dist.get_backend() if dist.is_initialized() else None,
+                     'world': dist.get_world_size() if dist.is_initialized() else 1,
+                     'collective': bool(dp.reducer.collective), 'bucket_bytes': int(dp.reducer.bucket_elems * 4)},
         }
         mp = measured_peaks(dev, args.dtype)
         roof['measured_peak'] = mp
         roof['frac_of_measured_gemm'] = round(ach / mp['library_gemm_8192_tflops'], 4)
-        out['roofline']['traffic_source'] = 'profiles/r02_pmc_traffic.json (null unless collected on these kernel sources)'
+        out['roofline']['traffic_source'] = 'profiles/%s (null unless collected on these kernel sources)' % PMC_FILE
     # the other 16-bit type on the same workload (configs[3] names bf16): a short secondary measurement, every rank takes part
     other = {'f16': 'bf16', 'bf16': 'f16'}.get(args.dtype)
     if other and not args.no_inference:

@@ -1326,6 +1326,17 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         }                                                                                                    \
         return CALL;                                                                                         \
     } while (0)
+    // the ws kernels: the name carries the instantiation's own template arguments <T, WM, KS, EPIK> (a profile symbol is then
+    // matched exactly); the tile is in tile_m / tile_n
+#define DBX_SELECT_WS(TM, TN, WMV, KSV, EPIKV, CALL)                                                         \
+    do {                                                                                                     \
+        if (plan) {                                                                                          \
+            plan->kernel = DBX_K_WS; plan->tile_m = TM; plan->tile_n = TN; plan->w_frag = 1;                 \
+            snprintf(plan->name, sizeof plan->name, "conv3x3_ws_kernel<%s,%d,%d,%d>", tname, WMV, KSV, EPIKV); \
+            return DBX_OK;                                                                                   \
+        }                                                                                                    \
+        return CALL;                                                                                         \
+    } while (0)
     const int ho = x->h + 2 * d->cpad - d->kh + 1, wo = x->w + 2 * d->cpad - d->kw + 1;
     DBX_REQUIRE(ho == y->h && wo == y->w && x->n == y->n, "conv: output %dx%d does not match %dx%d", y->h, y->w, ho, wo);
     DBX_REQUIRE(x->pad >= d->cpad, "conv: input frame %d < conv padding %d", x->pad, d->cpad);
@@ -1432,10 +1443,10 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         if (ws_ok && (wfrag || (plan && (ws_pref || ws_level() >= 2)))) {
             a.ntile_n = ctot / (256 / wm);
             if (k1 && !y2 && (a.epi & ~DBX_EPI_ACCUM) == (DBX_EPI_BIAS | DBX_EPI_DROPHASH) && ws_level() != 3)      // heads forward: fixed epilogue
-                DBX_SELECT(DBX_K_WS, 256, 256, "conv1x1_ws_kernel", (launch_conv_ws<T, 1, 1, 1>(a, x->n, x->h, x->pad, s)));
-            if (k1) DBX_SELECT(DBX_K_WS, 256, 256, "conv1x1_ws_kernel", (launch_conv_ws<T, 1, 1>(a, x->n, x->h, x->pad, s)));
-            if (wm == 1) DBX_SELECT(DBX_K_WS, 256, 256, "conv3x3_ws_kernel", (launch_conv_ws<T, 1, 3>(a, x->n, x->h, 1, s)));
-            DBX_SELECT(DBX_K_WS, 512, 128, "conv3x3_ws_kernel", (launch_conv_ws<T, 2, 3>(a, x->n, x->h, 1, s)));
+                DBX_SELECT_WS(256, 256, 1, 1, 1, (launch_conv_ws<T, 1, 1, 1>(a, x->n, x->h, x->pad, s)));
+            if (k1) DBX_SELECT_WS(256, 256, 1, 1, 0, (launch_conv_ws<T, 1, 1>(a, x->n, x->h, x->pad, s)));
+            if (wm == 1) DBX_SELECT_WS(256, 256, 1, 3, 0, (launch_conv_ws<T, 1, 3>(a, x->n, x->h, 1, s)));
+            DBX_SELECT_WS(512, 128, 2, 3, 0, (launch_conv_ws<T, 2, 3>(a, x->n, x->h, 1, s)));
         }
     }
     // 3x3 / pad 1 on congruent frames (x.pad == 1), 16-bit, plain NHWC epilogue: the band kernel over the linearised frame
@@ -1518,6 +1529,7 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
 }
 
 #undef DBX_SELECT
+#undef DBX_SELECT_WS
 
 extern "C" int dbx_conv_forward(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
                                 const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int32_t dropmask_ld,

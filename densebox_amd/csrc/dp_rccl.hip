@@ -6,7 +6,18 @@
 #include "common.hpp"
 #include <dlfcn.h>
 #include <string.h>
-#include <rccl/rccl.h>
+
+// The handful of RCCL (NCCL-API) types the four entry points use, declared here instead of including <rccl/rccl.h>: the library
+// then builds on a box without the RCCL development headers, as its "no link-time dependency" promises.  Values are the NCCL
+// ABI's (nccl.h: ncclSuccess = 0, ncclFloat32 = 7, ncclSum = 0, NCCL_UNIQUE_ID_BYTES = 128).
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclFloat = 7;
+static const ncclRedOp_t ncclSum = 0;
 
 namespace {
 struct Rccl {

@@ -88,6 +88,10 @@ __device__ __forceinline__ void block_argmax_cached(float bv, int bi, float* red
 #define NMS_LDS_MAX 1024
 __device__ void nms_block(const double* dets, int n, int dc, double thresh, int* keep, int* order, unsigned char* supp) {
     const int tid = threadIdx.x, nt = blockDim.x;
+    // (NaN scores compare false both ways: the ranks below are then not a permutation -- a diverged network must give a strange
+    // order, never an out-of-range row index: every slot starts as a valid row)
+    for (int i = tid; i < n; i += nt) order[i] = i;
+    __syncthreads();
     for (int i = tid; i < n; i += nt) {
         const double si = dets[(size_t)i * dc + 4];
         int rank = 0;

@@ -97,12 +97,15 @@ def detect(net, image, K=10, nms_thresh=0.4):
         # Read straight from the sub-modules' parameter dicts (sees in-place updates, .to()/.half() and replaced Parameter
         # objects; 12 us instead of the 75 us Module.parameters() spends walking the tree); the list of dicts itself is
         # rebuilt every 64 calls in case a whole sub-module was swapped.
+        # A replaced sub-module (net.conv6_3_det = nn.Conv2d(...)) changes the DIRECT children's identities: their ids are part
+        # of the signature (one dict walk), and the cached list is rebuilt whenever they differ.
+        kids = tuple(id(m) for m in net._modules.values())
         pd = net.__dict__.get('_detect_pdicts')
-        if pd is None or pd[0] <= 0:
-            pd = [64, [m._parameters for m in net.modules() if m._parameters]]
+        if pd is None or pd[0] <= 0 or pd[2] != kids:
+            pd = [64, [m._parameters for m in net.modules() if m._parameters], kids]
             net.__dict__['_detect_pdicts'] = pd
         pd[0] -= 1
-        sig = tuple([(p._version, p.data_ptr()) for d in pd[1] for p in d.values() if p is not None])
+        sig = (kids,) + tuple([(p._version, p.data_ptr()) for d in pd[1] for p in d.values() if p is not None])
         key = (tuple(image.shape), image.dtype, K, float(nms_thresh), net.resolved_dtype(False))
         ent = cache.get(key)
         if ent is None or ent[0] != sig:

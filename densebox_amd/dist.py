@@ -76,7 +76,11 @@ class GradReducer:
         self._works = []
 
     def ready(self, names):
-        """Called by the engine right after the kernels producing these gradients were enqueued."""
+        """Called by the engine right after the kernels producing these gradients were enqueued.  Outside DataParallel.step()
+        (a plain ``loss.backward()`` on a wrapped module) nothing is sent: there is no begin() / finish() around that backward, and
+        autograd hands out clones of the flat views while an in-place collective would still be running on them."""
+        if not self.in_step:
+            return
         for n in names:
             self._ready_hi = max(self._ready_hi, self.range[n][1])
         if self.collective and self._ready_hi - self._sent_hi >= self.bucket_elems:

@@ -70,14 +70,19 @@ class Plan:
         self.kind, self.n, self.h, self.w, self.dtype_id, self.train = kind, n, h, w, dtype_id, train
         es = _lib.ESIZE[dtype_id]
         self.cin0 = 16 // es                      # conv1_1 input channels padded to one 16-byte chunk
-        self.crf = 8 if es == 2 else 32           # refine input channels (5) padded: 16 B chunk, or a 128 B K step in f32
+        # refine branch (cat(landmarks, score) -> pool -> 3x3 -> 5x5 -> bilinear -> 1x1; 61 MMAC per patch): in eval mode it runs on the
+        # exact-fp32 MFMA path whatever the compute type -- its input ARE the fp32 head outputs, and rounding them and two more conv
+        # layers to 16 bits made the refined score the worst map of the 16-bit forward (2.8e-3 of max|ref| in f16); training keeps the
+        # compute type (three more f32 GEMM passes per step would cost 0.4 ms)
+        self.rdt = _lib.F32 if not train else dtype_id
+        self.crf = 8 if _lib.ESIZE[self.rdt] == 2 else 32    # refine input channels (5) padded: 16 B chunk, or a 128 B K step in f32
         nh = len(_HEADS[kind])
         h2, w2, h4, w4, h8, w8 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
         self.h4, self.w4 = h4, w4
         B = {}
 
-        def add(name, hh, ww, c, pad=1):
-            B[name] = Buf(name, n, hh, ww, c, pad, dtype_id)
+        def add(name, hh, ww, c, pad=1, dt=None):
+            B[name] = Buf(name, n, hh, ww, c, pad, dtype_id if dt is None else dt)
         add('x0', h, w, self.cin0)
         add('a11', h, w, 64); add('a12', h, w, 64); add('p1', h2, w2, 64)
         add('a21', h2, w2, 128); add('a22', h2, w2, 128); add('p2', h4, w4, 128)
@@ -89,11 +94,11 @@ class Plan:
         if kind != 'DenseBox':
             # frames chosen so that each conv's (dz, x) pair is congruent for the weight gradient AND dz has the
             # k-1 pixel frame its data gradient needs: rf_p(+1) ~ d_rf_1(+2), rf_1(+2) ~ d_rf_2(+4)
-            add('rf_in', h4, w4, self.crf, pad=0)
-            add('rf_p', h8, w8, self.crf, pad=1)
-            add('rf_1', h8 - 2, w8 - 2, 64, pad=2)
-            add('rf_2', h8 - 6, w8 - 6, 64, pad=0)
-            add('rf_u', h4, w4, 64, pad=0)
+            add('rf_in', h4, w4, self.crf, pad=0, dt=self.rdt)
+            add('rf_p', h8, w8, self.crf, pad=1, dt=self.rdt)
+            add('rf_1', h8 - 2, w8 - 2, 64, pad=2, dt=self.rdt)
+            add('rf_2', h8 - 6, w8 - 6, 64, pad=0, dt=self.rdt)
+            add('rf_u', h4, w4, 64, pad=0, dt=self.rdt)
         if train:
             # gradients (dZ = dL/d pre-activation) live in frames congruent to the matching activation
             for nm in ('a11', 'a12', 'a21', 'a22', 'a31', 'a32', 'a41', 'a42', 'a43', 'a44'):
@@ -283,9 +288,11 @@ class Engine:
             self._w_fwd(dt, 'conv5_2_' + s_, 512, 64)
             self._bias(['conv5_2_' + s_], 64)
         if kind != 'DenseBox':
-            self._w_fwd(dt, 'conv6_1_det', P.crf, 64); self._bias(['conv6_1_det'], 64)
-            self._w_fwd(dt, 'conv6_2_det', 64, 64); self._bias(['conv6_2_det'], 64)
-            self._w_fwd(dt, 'conv6_3_det', 64, 64); self._bias(['conv6_3_det'], 64)
+            if P.rdt == dt:       # (eval mode packs the fp32 refine weights on their own: the table is one dtype)
+                self._w_fwd(dt, 'conv6_1_det', P.crf, 64)
+                self._w_fwd(dt, 'conv6_2_det', 64, 64)
+                self._w_fwd(dt, 'conv6_3_det', 64, 64)
+            self._bias(['conv6_1_det'], 64); self._bias(['conv6_2_det'], 64); self._bias(['conv6_3_det'], 64)
         if train:
             for stem, cin, cout in _BACKBONE[1:]:
                 self._w_bwd(dt, stem, max(64, cin), cout, frag=self._frag(P, dt, stem, 'b'))
@@ -375,7 +382,9 @@ class Engine:
                 r = self.conv_plan(dt, vw(src), vw(dst), 3, 3, 1, cin_pad, max(64, cout), _lib.EPI_BIAS | _lib.EPI_RELU)[2]
             else:
                 dz, dx = _BWD_IO.get(stem, (None, None))           # conv1_1 has no data gradient
-                r = self.conv_plan(dt, vw(dz), vw(dx), 3, 3, 1, cout, max(64, cin), _lib.EPI_GATE)[2] if dz in B else False
+                # the epilogue of the real call: ReLU-gated, except the data gradients that feed a pooling layer (conv2_1, conv3_1, conv4_1)
+                gated = stem not in ('conv2_1_1', 'conv3_1_1', 'conv4_1_1')
+                r = self.conv_plan(dt, vw(dz), vw(dx), 3, 3, 1, cout, max(64, cin), _lib.EPI_GATE if gated else 0)[2] if dz in B else False
             P.frag[key] = r
         return r
 
@@ -550,18 +559,23 @@ class Engine:
                 outs[stem] = o
         if kind != 'DenseBox':
             # refine branch: cat(landmarks, score) -> pool4 -> 3x3 -> 5x5 -> bilinear -> 1x1   (DenseBox.py:464-471)
+            rdt = P.rdt
+            saved, self._defer = self._defer, None            # (fp32 refine weights: packed on their own, cached on the parameter versions)
+            w61, w62, w63 = (self._w_fwd(rdt, 'conv6_1_det', P.crf, 64), self._w_fwd(rdt, 'conv6_2_det', 64, 64),
+                             self._w_fwd(rdt, 'conv6_3_det', 64, 64))
+            self._defer = saved
             rin = B['rf_in'].view()
-            check(L.dbx_nchw_to_framed_ch(dt, ptr(outs['landmark']), 4, C.byref(rin), 0, s))
-            check(L.dbx_nchw_to_framed_ch(dt, ptr(outs['det']), 1, C.byref(rin), 4, s))
-            check(L.dbx_maxpool2x2(dt, C.byref(rin), C.byref(B['rf_p'].view()), s))
-            self._conv(dt, B['rf_p'].view(), B['rf_1'].view(), self._w_fwd(dt, 'conv6_1_det', P.crf, 64),
+            check(L.dbx_nchw_to_framed_ch(rdt, ptr(outs['landmark']), 4, C.byref(rin), 0, s))
+            check(L.dbx_nchw_to_framed_ch(rdt, ptr(outs['det']), 1, C.byref(rin), 4, s))
+            check(L.dbx_maxpool2x2(rdt, C.byref(rin), C.byref(B['rf_p'].view()), s))
+            self._conv(rdt, B['rf_p'].view(), B['rf_1'].view(), w61,
                        self._bias(['conv6_1_det'], 64), 3, 3, 0, P.crf, 64, _lib.EPI_BIAS, alg_ci=5)
-            self._conv(dt, B['rf_1'].view(), B['rf_2'].view(), self._w_fwd(dt, 'conv6_2_det', 64, 64),
+            self._conv(rdt, B['rf_1'].view(), B['rf_2'].view(), w62,
                        self._bias(['conv6_2_det'], 64), 5, 5, 0, 64, 64, _lib.EPI_BIAS)
-            check(L.dbx_upsample_bilinear(dt, C.byref(B['rf_2'].view()), C.byref(B['rf_u'].view()), s))
+            check(L.dbx_upsample_bilinear(rdt, C.byref(B['rf_2'].view()), C.byref(B['rf_u'].view()), s))
             o = torch.empty((n, 1, h4, w4), dtype=torch.float32, device=dev)
             yv = View(C.c_void_p(o.data_ptr()), n, h4, w4, 0, 1, 0, 1)
-            self._conv(dt, B['rf_u'].view(), yv, self._w_fwd(dt, 'conv6_3_det', 64, 64),
+            self._conv(rdt, B['rf_u'].view(), yv, w63,
                        self._bias(['conv6_3_det'], 64), 1, 1, 0, 64, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
             outs['refine'] = o
         return outs

@@ -47,3 +47,62 @@ def test_detect_1080p(golden):
     assert dets.shape == (10, 5) and dets.dtype == np.float64
     assert np.allclose(dets, g['dets'], rtol=1e-4, atol=2e-3)
     assert keep == list(g['keep'])
+
+
+def test_detect_graph_replay_across_shapes_and_training():
+    """detect() caches one hipGraph per (shape, K, dtype, weights): shapes A, B, A again, then a training step that changes the
+    weights, then A -- every replayed result must equal the eager result of the same call (round-1 advisor: a replay once read
+    buffers a later shape had re-planned)."""
+    import os
+    import densebox_amd as D
+    from densebox_amd import synth, labels as LB
+    from densebox_amd.optim import SGD
+    net = D.DenseBoxLMLOC(synth.vgg19_standin(seed=0))
+    synth.fill_params_(net, 11)
+    net = net.cuda().eval()
+    net.compute_dtype = 'f16'
+    xa = synth.synth_images(1, 240, 240, seed=1).cuda()
+    xb = synth.synth_images(1, 192, 320, seed=2).cuda()
+
+    def both(x, K):
+        os.environ['DBX_GRAPH'] = '0'
+        try:
+            de, ke = net.detect(x, K=K, nms_thresh=0.4)
+        finally:
+            os.environ.pop('DBX_GRAPH', None)
+        dg, kg = net.detect(x, K=K, nms_thresh=0.4)       # first call captures, later calls replay
+        dg2, kg2 = net.detect(x, K=K, nms_thresh=0.4)
+        assert np.array_equal(np.asarray(de), np.asarray(dg)) and list(ke) == list(kg), 'graph != eager'
+        assert np.array_equal(np.asarray(dg), np.asarray(dg2)) and list(kg) == list(kg2), 'replay != capture'
+        return np.asarray(de).copy()
+    a1 = both(xa, 10)
+    b1 = both(xb, 10)
+    a2 = both(xa, 10)                                     # back to A: its graph must still own valid buffers
+    assert np.array_equal(a1, a2)
+    b2 = both(xb, 25)                                     # another K on shape B
+    assert b2.shape[0] == 25 and b1.shape[0] == 10
+    # a training step in between: new weights, new plan -- the cached graphs must notice and re-capture
+    net.train()
+    net.compute_dtype = 'f16'
+    opt = SGD(net.parameters(), lr=2e-9, momentum=0.9, weight_decay=5e-8)
+    x, bbox, vert, lab = synth.synth_batch(2, seed=7, neg_frac=0.0)
+    outs = net(x.cuda())
+    loss = net.loss(outs, bbox, vert, lab)
+    loss.backward()
+    opt.step()
+    net.eval()
+    a3 = both(xa, 10)
+    assert not np.array_equal(a1, a3), 'detections did not change after a weight update (stale graph)'
+
+
+def test_nms_and_detect_survive_nan_scores():
+    """A diverged network (NaN / Inf maps) must not turn into an out-of-range row index on the GPU (found in round 3: NaN scores
+    made the rank sort of the NMS a non-permutation and the kernel read dets[garbage])."""
+    d = np.random.RandomState(0).rand(40, 5) * 100
+    d[:, 2:4] += d[:, 0:2]
+    d[::3, 4] = np.nan
+    keep = DC.NMS(d, 0.4)
+    assert all(0 <= k < 40 for k in keep)
+    s = torch.full((1, 1, 60, 60), float('nan')); l = torch.zeros(1, 4, 60, 60)
+    out = DC.parse_out_MN(s.cuda(), l.cuda(), 240, 240, K=10)
+    assert out.shape == (10, 5)

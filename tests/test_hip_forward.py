@@ -2,10 +2,12 @@
 
 Tolerances (outputs are O(1); loc-type outputs O(10)):
   f32  : |err| <= 1e-4 * max(1, |ref|)   exact-fp32 MFMA, only summation order differs
-  f16  : fp16 activation rounding accumulated over 13 layers.  Achieved (profiles/r02_lowprec_errors.json, tools/gpu_lowprec_err.py):
-         bbox / landmark-offset maps 0.6-1.0e-3, score / heat maps 1.3-1.7e-3, the refine score (two more convs) 2.8e-3 of
-         max|ref|; rms 2-9e-4.  Checked as achieved + 20 %: 3.4e-3 * max|ref|
-  bf16 : 8x coarser mantissa: achieved 0.6-1.2e-2, refine score 2.7e-2 -> 3e-2 * max|ref|
+  f16  : fp16 activation rounding accumulated over 13 layers.  Achieved (profiles/r03_lowprec_errors.json, tools/gpu_lowprec_err.py):
+         bbox / landmark-offset maps 0.7-0.8e-3, score / heat maps 1.4-1.9e-3, the refined score of DenseBoxLMLOC 3.1e-3 of max|ref|
+         (its INPUTS, the f16 head outputs, carry 1.5-1.9e-3 and its three convs amplify that: running the branch itself in fp32 --
+         eval mode does since round 3 -- left it where it was; DenseBoxLM's refined score is 1.5e-3).  MAX error bar = achieved + 20 %:
+         3.8e-3 * max|ref|; RMS error bar 1e-3 (north_star's figure; achieved 2-9e-4 on every map)
+  bf16 : 8x coarser mantissa: achieved 0.6-1.4e-2 -> max bar 2e-2, RMS bar 8e-3
 """
 import numpy as np
 import pytest
@@ -18,7 +20,8 @@ import densebox_amd as D
 pytestmark = pytest.mark.gpu
 
 KINDS = ['DenseBox', 'DenseBoxLM', 'DenseBoxLMLOC']
-TOL = {'f32': 1e-4, 'f16': 3.4e-3, 'bf16': 3e-2}
+TOL = {'f32': 1e-4, 'f16': 3.8e-3, 'bf16': 2e-2}
+RMS_TOL = {'f32': 2e-5, 'f16': 1e-3, 'bf16': 8e-3}        # per-map RMS error / max(1, max|ref|)
 
 
 def _net(kind, dtype, seed=11):
@@ -29,12 +32,15 @@ def _net(kind, dtype, seed=11):
     return net
 
 
-def _close(a, ref, tol, what):
+def _close(a, ref, tol, what, rms_tol=None):
     a = a.detach().float().cpu().numpy()
     scale = max(1.0, float(np.abs(ref).max()))
     err = float(np.abs(a - ref).max())
     assert a.shape == ref.shape, (what, a.shape, ref.shape)
     assert err <= tol * scale, '%s: max err %.3e > %.1e * %.2f' % (what, err, tol, scale)
+    if rms_tol is not None:
+        rms = float(np.sqrt(np.mean((a.astype(np.float64) - ref) ** 2)))
+        assert rms <= rms_tol * scale, '%s: rms err %.3e > %.1e * %.2f' % (what, rms, rms_tol, scale)
     return err
 
 
@@ -48,7 +54,7 @@ def test_forward_vs_reference_fixture(golden, kind, dtype):
     assert len(outs) == sum(1 for k in g.files if k.startswith('out240_'))
     for i, o in enumerate(outs):
         assert o.dtype == torch.float32 and o.is_contiguous()
-        _close(o, g['out240_%d' % i], TOL[dtype], '%s/%s out %d' % (kind, dtype, i))
+        _close(o, g['out240_%d' % i], TOL[dtype], '%s/%s out %d' % (kind, dtype, i), RMS_TOL[dtype])
     # intermediate taps (first conv + first pool) pin the layer kernels individually
     eng = net.engine()
     a11 = eng.read_activation('a11')[0, ::8, ::6, ::6]

@@ -320,7 +320,7 @@ def test_conv_ws_1x1_forward_bias_and_hash_dropout(dtn):
             d = ConvDesc(dt, 1, 1, 0, ci, co, epi, 0x1234)
             plan = _lib.ConvPlan()
             check(L.dbx_conv_plan(C.byref(d), C.byref(xv), C.byref(yv), C.byref(plan)))
-            assert plan.kernel == _lib.K_WS and plan.name.decode().startswith('conv1x1_ws_kernel<')
+            assert plan.kernel == _lib.K_WS and plan.name.decode().startswith('conv3x3_ws_kernel<') and ',1,1,' in plan.name.decode()
             if frag:
                 d = ConvDesc(dt, 1, 1, 0, ci, co, epi | _lib.CONV_WFRAG, 0x1234)
             check(L.dbx_conv_forward(C.byref(d), C.byref(xv), ptr(pack(L, dt, wt, ci, co, mode=4 if frag else 0)), ptr(b), C.byref(yv),
