@@ -999,15 +999,43 @@ __global__ void pack_multi_kernel(const PackJob* __restrict__ jobs) {
     const PackJob j = jobs[blockIdx.y];
     const int total = j.co * j.ci * j.taps, taps = j.taps, ci = j.ci;           // (a layer has < 2^31 weights: 32-bit index math)
     T* wp = (T*)j.dst;
+    const bool fwd = j.mode == 0 || j.mode == 4;
+    const int rl = j.mode >= 4 ? (int)j.ktot : j.rows_lim;
+    if (sizeof(T) == 2 && j.mode != 2 && (fwd ? ci : j.co) % 8 == 0 && (j.k_off & 7) == 0 && (j.cin_pad & 7) == 0) {
+        // 16-bit weights whose packed K index runs over a multiple of 8 source channels: a thread owns one 16-BYTE chunk of the
+        // destination (eight consecutive K elements: input channels of one (row, tap) in the forward layouts, output channels in the
+        // transposed ones -- contiguous in the plain AND the fragment-order image), gathers its eight fp32 sources (L2-resident:
+        // every byte of the 47 MB of parameters is used by some thread) and writes once, coalesced.  The element-wise loop below
+        // wrote 2 bytes per lane to scattered addresses (130 us per step for all parameters; this: ~35 us).
+        const int inner = (fwd ? ci : j.co) / 8, outer = fwd ? j.co : ci;
+        const int chunks = outer * taps * inner;
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += gridDim.x * blockDim.x) {
+            const int k8 = i % inner, q = i / inner, t = q % taps, r = q / taps;       // r: destination row's source index (o fwd, c bwd)
+            const int row = j.row_off + r, col = j.k_off + 8 * k8, tap = fwd ? t : taps - 1 - t;
+            if (row < 0 || col < 0 || col + 8 > j.cin_pad || (rl > 0 && row >= rl)) continue;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int o = fwd ? r : 8 * k8 + e, c = fwd ? 8 * k8 + e : r;
+                v[e] = j.src[(o * ci + c) * taps + t];
+            }
+            u32x4 raw;
+            T* e8 = (T*)&raw;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) e8[e] = from_f32<T>(v[e]);
+            const long long di = j.mode >= 4 ? (long long)dbx_frag_index(row, tap, col, j.cin_pad, (int)j.ktot, taps)
+                                             : (long long)row * j.ktot + (long long)tap * j.cin_pad + col;
+            *(u32x4*)(wp + di) = raw;
+        }
+        return;
+    }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const float v = j.src[i];
         if (j.mode == 2) { ((float*)j.dst)[j.row_off + i] = v; continue; }        // bias: plain copy into the padded vector
         const int q = i / taps, t = i - q * taps;
         const int o = q / ci, c = q - o * ci;
         {   // an element whose destination lies outside the packed matrix is skipped: negative offsets cut a channel range out of a wider tensor
-            const bool fwd = j.mode == 0 || j.mode == 4;
             const int row = j.row_off + (fwd ? o : c), col = j.k_off + (fwd ? c : o);
-            const int rl = j.mode >= 4 ? (int)j.ktot : j.rows_lim;
             if (row < 0 || col < 0 || col >= j.cin_pad || (rl > 0 && row >= rl)) continue;
         }
         if (j.mode == 0) wp[(long long)(j.row_off + o) * j.ktot + (long long)t * j.cin_pad + j.k_off + c] = from_f32<T>(v);

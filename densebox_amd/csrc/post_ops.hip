@@ -163,13 +163,22 @@ struct DetArgs {
     double* dets; long long* topk; int* keep; float* work; int* order; unsigned char* supp;
 };
 
+// order-preserving key of a score for the radix select: larger float <-> larger key, -0 == +0, NaN below every number
+__device__ __forceinline__ unsigned det_key(float v) {
+    if (v != v) return 0u;
+    if (v == 0.f) return 0x80000000u;
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
 __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
     __shared__ float red_v[DET_THREADS / 64];
     __shared__ int red_i[DET_THREADS / 64];
     __shared__ int lm_arg[4];
     const int tid = threadIdx.x, n = a.rows * a.cols;
-    for (int i = tid; i < n; i += DET_THREADS) a.work[i] = a.score[i];
-    __syncthreads();
+    constexpr int BK = 64, NB_MAX = 4096;
+    __shared__ float bmax[NB_MAX];
+    __shared__ int bidx[NB_MAX];
     // landmark arg-max per heat-map channel (parse_DetLM, DenseBox.py:3284-3292): identical for every detection
     if (a.lm_heat && !a.lm_loc) {
         for (int j = 0; j < 4; ++j) {
@@ -179,81 +188,160 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
         }
         __syncthreads();
     }
-    // K rounds of arg-max over a two-level structure: LDS holds the (max, arg-max) of every bucket of 64 consecutive scores;
-    // a round reduces the bucket maxima (LDS only) and one wave re-scans the winner's bucket (64 loads in flight at once),
-    // instead of every thread re-reading its share of the whole map from global memory: ~4 us per round instead of 24.
-    // Same order as a full scan: larger value first, lower index on ties, NaN never beats a number.
-    constexpr int BK = 64, NB_MAX = 4096;
-    __shared__ float bmax[NB_MAX];
-    __shared__ int bidx[NB_MAX];
-    const int nb = (n + BK - 1) / BK;
-    const int lane = tid & 63, wv = tid >> 6;
-    const bool two_level = nb <= NB_MAX;
-    auto scan_bucket = [&](int b) {                              // one wave: arg-max of bucket b -> LDS
-        const int i = b * BK + lane;
-        float v = i < n ? a.work[i] : -INFINITY; int vi = i < n ? i : 0x7fffffff;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const float v2 = __shfl_down(v, off); const int i2 = __shfl_down(vi, off);
-            if (i2 != 0x7fffffff && (vi == 0x7fffffff || v2 > v || (v2 == v && i2 < vi))) { v = v2; vi = i2; }
-        }
-        if (lane == 0) { bmax[b] = v; bidx[b] = vi; }
-    };
-    if (two_level) {
-        for (int b = wv; b < nb; b += DET_THREADS / 64) scan_bucket(b);
+    // ---- top-K indices into a.topk, in the reference's order: larger score first, lower index on ties
+    const bool select = a.K > 48 && a.K <= DET_THREADS;
+    if (select) {
+        // K in (48, 1024] (round 3: K = 1000 at 1080p took 4.7 ms as 1000 arg-max rounds): radix select of the K-th largest key
+        // (four 8-bit passes, LDS histogram), compaction of the keys above it plus the lowest-index ties, bitonic sort of <= 1024
+        // (key, index) pairs in LDS -- ~0.1 ms, the same ranking bit for bit.
+        unsigned* hist = (unsigned*)bmax;                        // [256]
+        unsigned long long* cand = (unsigned long long*)bidx;    // [1024] (key << 32) | ~index: descending sort = reference order
+        __shared__ unsigned sel_prefix, sel_remaining, sel_ties, cand_n, tie_base[DET_THREADS / 64 + 1];
+        if (tid == 0) { sel_prefix = 0; sel_remaining = (unsigned)a.K; }
         __syncthreads();
-    }
-    float bv = -INFINITY; int bi = 0x7fffffff;
-    auto rescan = [&]() {                                        // fallback for huge maps: per-thread cached candidate
-        bv = -INFINITY; bi = 0x7fffffff;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            if (tid < 256) hist[tid] = 0;
+            __syncthreads();
+            const unsigned prefix = sel_prefix;
+            for (int i = tid; i < n; i += DET_THREADS) {
+                const unsigned k = det_key(a.score[i]);
+                if (pass == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned rem = sel_remaining, b = 255;
+                for (;; --b) { const unsigned c = hist[b]; if (c >= rem || b == 0) break; rem -= c; }
+                sel_prefix = prefix | (b << shift); sel_remaining = rem; sel_ties = hist[b];
+            }
+            __syncthreads();
+        }
+        const unsigned T = sel_prefix, need = sel_remaining, ties = sel_ties;     // K-th key; how many of its `ties` copies are taken
+        if (tid == 0) cand_n = 0;
+        __syncthreads();
         for (int i = tid; i < n; i += DET_THREADS) {
-            const float v = a.work[i];
-            if (v > bv || bi == 0x7fffffff) { bv = v; bi = i; }
+            const unsigned k = det_key(a.score[i]);
+            if (k > T || (k == T && ties == need)) {
+                const unsigned slot = atomicAdd(&cand_n, 1u);
+                cand[slot] = ((unsigned long long)k << 32) | (unsigned)(~(unsigned)i);
+            }
         }
-    };
-    if (!two_level) rescan();
-    for (int k = 0; k < a.K; ++k) {
-        float v; int idx;
+        __syncthreads();
+        if (ties != need) {
+            // more copies of the K-th score than places: the lowest indices win.  Thread t owns the contiguous index range
+            // [t * seg, (t + 1) * seg): per-thread tie counts -> exclusive block scan -> the first `need` ties in index order.
+            const int seg = (n + DET_THREADS - 1) / DET_THREADS, lo = tid * seg, hi = min(n, lo + seg);
+            unsigned mine = 0;
+            for (int i = lo; i < hi; ++i) mine += det_key(a.score[i]) == T;
+            unsigned incl = mine;                                   // inclusive scan inside the wave
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(incl, off); if ((tid & 63) >= off) incl += o; }
+            if ((tid & 63) == 63) tie_base[(tid >> 6) + 1] = incl;
+            __syncthreads();
+            if (tid == 0) { tie_base[0] = 0; for (int w = 1; w <= DET_THREADS / 64; ++w) tie_base[w] += tie_base[w - 1]; }
+            __syncthreads();
+            unsigned before = tie_base[tid >> 6] + incl - mine;
+            const unsigned base_slot = cand_n;
+            for (int i = lo; i < hi && before < need; ++i)
+                if (det_key(a.score[i]) == T) { cand[base_slot + before] = ((unsigned long long)T << 32) | (unsigned)(~(unsigned)i); ++before; }
+            __syncthreads();
+        }
+        for (int i = a.K + tid; i < DET_THREADS; i += DET_THREADS) cand[i] = 0ull;       // padding sorts last
+        __syncthreads();
+        // bitonic sort, descending, 1024 elements: one element per thread
+        for (int size = 2; size <= DET_THREADS; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const int partner = tid ^ stride;
+                const unsigned long long me = cand[tid], ot = cand[partner];
+                __syncthreads();
+                const bool desc = (tid & size) == 0;                // this block sorts descending
+                const bool keep_max = (tid < partner) == desc;
+                cand[tid] = keep_max ? (me > ot ? me : ot) : (me < ot ? me : ot);
+                __syncthreads();
+            }
+        }
+        if (tid < a.K) a.topk[tid] = (long long)(~(unsigned)(cand[tid] & 0xffffffffull));
+        __syncthreads();
+    } else {
+        for (int i = tid; i < n; i += DET_THREADS) a.work[i] = a.score[i];
+        __syncthreads();
+        // K rounds of arg-max over a two-level structure: LDS holds the (max, arg-max) of every bucket of 64 consecutive scores;
+        // a round reduces the bucket maxima (LDS only) and one wave re-scans the winner's bucket (64 loads in flight at once),
+        // instead of every thread re-reading its share of the whole map from global memory: ~4 us per round instead of 24.
+        // Same order as a full scan: larger value first, lower index on ties, NaN never beats a number.
+        const int nb = (n + BK - 1) / BK;
+        const int lane = tid & 63, wv = tid >> 6;
+        const bool two_level = nb <= NB_MAX;
+        auto scan_bucket = [&](int b) {                              // one wave: arg-max of bucket b -> LDS
+            const int i = b * BK + lane;
+            float v = i < n ? a.work[i] : -INFINITY; int vi = i < n ? i : 0x7fffffff;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float v2 = __shfl_down(v, off); const int i2 = __shfl_down(vi, off);
+                if (i2 != 0x7fffffff && (vi == 0x7fffffff || v2 > v || (v2 == v && i2 < vi))) { v = v2; vi = i2; }
+            }
+            if (lane == 0) { bmax[b] = v; bidx[b] = vi; }
+        };
         if (two_level) {
-            float cv = -INFINITY; int ci = 0x7fffffff;
-            for (int b = tid; b < nb; b += DET_THREADS) {
-                const float v2 = bmax[b]; const int i2 = bidx[b];
-                if (i2 != 0x7fffffff && (ci == 0x7fffffff || v2 > cv || (v2 == cv && i2 < ci))) { cv = v2; ci = i2; }
-            }
-            block_argmax_cached(cv, ci, red_v, red_i, v, idx);
-            if (wv == 0) {                                       // wave 0 retires the winner and refreshes its bucket
-                if (lane == 0) a.work[idx] = -INFINITY;
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
-                scan_bucket(idx / BK);
-            }
-        } else {
-            block_argmax_cached(bv, bi, red_v, red_i, v, idx);
-            if ((idx & (DET_THREADS - 1)) == tid) { a.work[idx] = -INFINITY; rescan(); }
+            for (int b = wv; b < nb; b += DET_THREADS / 64) scan_bucket(b);
+            __syncthreads();
         }
-        if (tid == 0) {
-            a.topk[k] = idx;
-            const float xi = (float)(idx % a.cols), yi = (float)(idx / a.cols);
-            double* d = a.dets + (size_t)k * a.dc;
-            // fp32 subtraction (python int - fp32 tensor), then float()*4.0 in double (DenseBox.py:3334-3343)
-            d[0] = (double)(xi - a.loc[idx]) * 4.0;
-            d[1] = (double)(yi - a.loc[(size_t)n + idx]) * 4.0;
-            d[2] = (double)(xi - a.loc[(size_t)2 * n + idx]) * 4.0;
-            d[3] = (double)(yi - a.loc[(size_t)3 * n + idx]) * 4.0;
-            d[4] = (double)a.score[idx];
-            if (a.dc == 13) {
-                if (a.lm_loc) {
-                    for (int c = 0; c < 8; ++c)
-                        d[5 + c] = (double)(((c & 1) ? yi : xi) - a.lm_loc[(size_t)c * n + idx]) * 4.0;   // :3183-3196
-                } else {
-                    for (int j = 0; j < 4; ++j) {
-                        d[5 + 2 * j] = (double)(float)(lm_arg[j] % a.cols) * 4.0;
-                        d[6 + 2 * j] = (double)(float)(lm_arg[j] / a.cols) * 4.0;
-                    }
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        auto rescan = [&]() {                                        // fallback for huge maps: per-thread cached candidate
+            bv = -INFINITY; bi = 0x7fffffff;
+            for (int i = tid; i < n; i += DET_THREADS) {
+                const float v = a.work[i];
+                if (v > bv || bi == 0x7fffffff) { bv = v; bi = i; }
+            }
+        };
+        if (!two_level) rescan();
+        for (int k = 0; k < a.K; ++k) {
+            float v; int idx;
+            if (two_level) {
+                float cv = -INFINITY; int ci = 0x7fffffff;
+                for (int b = tid; b < nb; b += DET_THREADS) {
+                    const float v2 = bmax[b]; const int i2 = bidx[b];
+                    if (i2 != 0x7fffffff && (ci == 0x7fffffff || v2 > cv || (v2 == cv && i2 < ci))) { cv = v2; ci = i2; }
+                }
+                block_argmax_cached(cv, ci, red_v, red_i, v, idx);
+                if (wv == 0) {                                       // wave 0 retires the winner and refreshes its bucket
+                    if (lane == 0) a.work[idx] = -INFINITY;
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                    scan_bucket(idx / BK);
+                }
+            } else {
+                block_argmax_cached(bv, bi, red_v, red_i, v, idx);
+                if ((idx & (DET_THREADS - 1)) == tid) { a.work[idx] = -INFINITY; rescan(); }
+            }
+            if (tid == 0) a.topk[k] = idx;
+            __syncthreads();
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- decode: one thread per detection (the rows no longer sit as dependent global loads inside the selection rounds)
+    for (int k = tid; k < a.K; k += DET_THREADS) {
+        const int idx = (int)a.topk[k];
+        const float xi = (float)(idx % a.cols), yi = (float)(idx / a.cols);
+        double* d = a.dets + (size_t)k * a.dc;
+        // fp32 subtraction (python int - fp32 tensor), then float()*4.0 in double (DenseBox.py:3334-3343)
+        d[0] = (double)(xi - a.loc[idx]) * 4.0;
+        d[1] = (double)(yi - a.loc[(size_t)n + idx]) * 4.0;
+        d[2] = (double)(xi - a.loc[(size_t)2 * n + idx]) * 4.0;
+        d[3] = (double)(yi - a.loc[(size_t)3 * n + idx]) * 4.0;
+        d[4] = (double)a.score[idx];
+        if (a.dc == 13) {
+            if (a.lm_loc) {
+                for (int c = 0; c < 8; ++c)
+                    d[5 + c] = (double)(((c & 1) ? yi : xi) - a.lm_loc[(size_t)c * n + idx]) * 4.0;   // :3183-3196
+            } else {
+                for (int j = 0; j < 4; ++j) {
+                    d[5 + 2 * j] = (double)(float)(lm_arg[j] % a.cols) * 4.0;
+                    d[6 + 2 * j] = (double)(float)(lm_arg[j] / a.cols) * 4.0;
                 }
             }
         }
-        __syncthreads();
     }
     __threadfence_block();
     __syncthreads();

@@ -70,11 +70,11 @@ class Plan:
         self.kind, self.n, self.h, self.w, self.dtype_id, self.train = kind, n, h, w, dtype_id, train
         es = _lib.ESIZE[dtype_id]
         self.cin0 = 16 // es                      # conv1_1 input channels padded to one 16-byte chunk
-        # refine branch (cat(landmarks, score) -> pool -> 3x3 -> 5x5 -> bilinear -> 1x1; 61 MMAC per patch): in eval mode it runs on the
-        # exact-fp32 MFMA path whatever the compute type -- its input ARE the fp32 head outputs, and rounding them and two more conv
-        # layers to 16 bits made the refined score the worst map of the 16-bit forward (2.8e-3 of max|ref| in f16); training keeps the
-        # compute type (three more f32 GEMM passes per step would cost 0.4 ms)
-        self.rdt = _lib.F32 if not train else dtype_id
+        # refine branch (cat(landmarks, score) -> pool -> 3x3 -> 5x5 -> bilinear -> 1x1; 61 MMAC per patch) runs in the compute type.
+        # Round 3 tried it on the exact-fp32 path in eval mode (its inputs ARE the fp32 head outputs): the refined score of
+        # DenseBoxLMLOC stayed the worst 16-bit map (3.1e-3 of max|ref| in f16 -- the error is in its inputs, the f16 head outputs, and
+        # its convs amplify it) while the three fp32 GEMMs added 0.1 ms to a 0.53 ms 512x512 inference: reverted (rdt == dtype).
+        self.rdt = dtype_id
         self.crf = 8 if _lib.ESIZE[self.rdt] == 2 else 32    # refine input channels (5) padded: 16 B chunk, or a 128 B K step in f32
         nh = len(_HEADS[kind])
         h2, w2, h4, w4, h8, w8 = h // 2, w // 2, h // 4, w // 4, h // 8, w // 8
@@ -251,6 +251,19 @@ class Engine:
             return out
         return self._packed(('heads1', mode, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
 
+    def _w_heads2(self, dt):
+        """Stage-2 head weights as one block-diagonal matrix [64 rows][512 nh]: head i's k_i rows at row sum(k_<i), columns 512 i .."""
+        heads = _HEADS[self.kind]
+        ws = [self._param('conv5_2_%s.weight' % s) for s, _ in heads]
+
+        def build(out):
+            r = 0
+            for i, (w, (_, k)) in enumerate(zip(ws, heads)):
+                out = self._pack(dt, 0, w, 64, 512 * len(ws), 1, 1, out=out, row_off=r, k_off=512 * i)
+                r += k
+            return out
+        return self._packed(('heads2', 0, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+
     def _frag_heads(self, P, dt, which):
         """Fragment-order weights for the heads' 768 -> 512 nh GEMM ('f') / its split-destination data gradient ('b')?"""
         key = ('heads1', which)
@@ -284,9 +297,8 @@ class Engine:
             self._bias([stem], max(64, cout))
         self._w_heads1(dt, frag=train and self._frag_heads(P, dt, 'f'))
         self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
-        for s_, _ in heads:
-            self._w_fwd(dt, 'conv5_2_' + s_, 512, 64)
-            self._bias(['conv5_2_' + s_], 64)
+        self._w_heads2(dt)
+        self._bias(['conv5_2_' + s_ for s_, _ in heads], 64)
         if kind != 'DenseBox':
             if P.rdt == dt:       # (eval mode packs the fp32 refine weights on their own: the table is one dtype)
                 self._w_fwd(dt, 'conv6_1_det', P.crf, 64)
@@ -551,12 +563,17 @@ class Engine:
                        self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh), 1, 1, 0, 768, 512 * nh,
                        epi | (_lib.CONV_WFRAG if hfrag else 0),
                        dropmask=dm, dm_ld=512 * nh, drop_seed=P.drop_seed if P.drop_hash else 0)
-            for i, (stem, k) in enumerate(heads):
-                o = torch.empty((n, k, h4, w4), dtype=torch.float32, device=dev)
-                yv = View(C.c_void_p(o.data_ptr()), n, h4, w4, 0, k, 0, k)
-                self._conv(dt, B['hid'].view(512 * i, 512), yv, self._w_fwd(dt, 'conv5_2_' + stem, 512, 64),
-                           self._bias(['conv5_2_' + stem], 64), 1, 1, 0, 512, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
-                outs[stem] = o
+            # stage 2: the nh Conv1x1(512 -> k) as ONE block-diagonal GEMM 512 nh -> sum(k) over the full hidden rows (4 KiB contiguous
+            # per pixel instead of four strided 1-KiB slices in four launches); the heads' outputs are channel ranges of one tensor
+            ktot = sum(k for _, k in heads)
+            big = torch.empty((n, ktot, h4, w4), dtype=torch.float32, device=dev)
+            yv = View(C.c_void_p(big.data_ptr()), n, h4, w4, 0, ktot, 0, ktot)
+            self._conv(dt, B['hid'].view(), yv, self._w_heads2(dt), self._bias(['conv5_2_' + s_ for s_, _ in heads], 64), 1, 1, 0,
+                       512 * nh, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW, alg_ci=512)
+            o = 0
+            for stem, k in heads:
+                outs[stem] = big[:, o:o + k].contiguous()
+                o += k
         if kind != 'DenseBox':
             # refine branch: cat(landmarks, score) -> pool4 -> 3x3 -> 5x5 -> bilinear -> 1x1   (DenseBox.py:464-471)
             rdt = P.rdt

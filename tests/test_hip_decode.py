@@ -106,3 +106,35 @@ def test_nms_and_detect_survive_nan_scores():
     s = torch.full((1, 1, 60, 60), float('nan')); l = torch.zeros(1, 4, 60, 60)
     out = DC.parse_out_MN(s.cuda(), l.cuda(), 240, 240, K=10)
     assert out.shape == (10, 5)
+
+
+@pytest.mark.parametrize('case', ['random', 'quantised', 'constant', 'signed_zero'])
+def test_topk_select_path_matches_rounds_and_reference_order(case):
+    """K in (48, 1024] takes the radix-select path: the ranking must be the round-based path's (K <= 48) bit for bit -- larger
+    score first, LOWER INDEX on ties -- also when the K-th score has more copies than places (ties cut by index), on all-equal
+    maps and for +0 / -0 (equal as floats)."""
+    rs = np.random.RandomState({'random': 1, 'quantised': 2, 'constant': 3, 'signed_zero': 4}[case])
+    rows, cols = 67, 120
+    n = rows * cols
+    if case == 'random':
+        sc = rs.randn(n).astype(np.float32)
+    elif case == 'quantised':
+        sc = (rs.randint(0, 7, size=n) / 4.0).astype(np.float32)          # 7 distinct values: hundreds of ties per value
+    elif case == 'constant':
+        sc = np.full(n, 0.25, np.float32)
+    else:
+        sc = np.where(rs.rand(n) < 0.5, np.float32(0.0), np.float32(-0.0)).astype(np.float32)
+        sc[rs.randint(0, n, 30)] = -1.0
+    loc = rs.randn(4, n).astype(np.float32)
+    s = torch.from_numpy(sc).view(1, 1, rows, cols).cuda()
+    l = torch.from_numpy(loc).view(1, 4, rows, cols).cuda()
+    # reference order: value descending, index ascending on ties (what K arg-max rounds with "lower index wins" produce)
+    order = np.lexsort((np.arange(n), -sc.astype(np.float64)))
+    for K in (40, 49, 300, 1000, 1024):
+        dets, topk, keep = DC._run(s, l, rows * 4, cols * 4, K)
+        got = topk.cpu().numpy()
+        assert np.array_equal(got, order[:K]), (case, K, np.nonzero(got != order[:K])[0][:5])
+        d = dets.cpu().numpy()
+        assert np.array_equal(d[:, 4], sc[order[:K]].astype(np.float64))
+        xi = (order[:K] % cols).astype(np.float32)
+        assert np.array_equal(d[:, 0], (xi - loc[0, order[:K]]).astype(np.float32).astype(np.float64) * 4.0)

@@ -4,8 +4,8 @@ Tolerances (outputs are O(1); loc-type outputs O(10)):
   f32  : |err| <= 1e-4 * max(1, |ref|)   exact-fp32 MFMA, only summation order differs
   f16  : fp16 activation rounding accumulated over 13 layers.  Achieved (profiles/r03_lowprec_errors.json, tools/gpu_lowprec_err.py):
          bbox / landmark-offset maps 0.7-0.8e-3, score / heat maps 1.4-1.9e-3, the refined score of DenseBoxLMLOC 3.1e-3 of max|ref|
-         (its INPUTS, the f16 head outputs, carry 1.5-1.9e-3 and its three convs amplify that: running the branch itself in fp32 --
-         eval mode does since round 3 -- left it where it was; DenseBoxLM's refined score is 1.5e-3).  MAX error bar = achieved + 20 %:
+         (its INPUTS, the f16 head outputs, carry 1.5-1.9e-3 and its three convs amplify that: running the branch itself in fp32 was
+         tried in round 3 and left it where it was; DenseBoxLM's refined score is 1.5e-3).  MAX error bar = achieved + 20 %:
          3.8e-3 * max|ref|; RMS error bar 1e-3 (north_star's figure; achieved 2-9e-4 on every map)
   bf16 : 8x coarser mantissa: achieved 0.6-1.4e-2 -> max bar 2e-2, RMS bar 8e-3
 """
