@@ -1001,31 +1001,51 @@ __global__ void pack_multi_kernel(const PackJob* __restrict__ jobs) {
     T* wp = (T*)j.dst;
     const bool fwd = j.mode == 0 || j.mode == 4;
     const int rl = j.mode >= 4 ? (int)j.ktot : j.rows_lim;
-    if (sizeof(T) == 2 && j.mode != 2 && (fwd ? ci : j.co) % 8 == 0 && (j.k_off & 7) == 0 && (j.cin_pad & 7) == 0) {
-        // 16-bit weights whose packed K index runs over a multiple of 8 source channels: a thread owns one 16-BYTE chunk of the
-        // destination (eight consecutive K elements: input channels of one (row, tap) in the forward layouts, output channels in the
-        // transposed ones -- contiguous in the plain AND the fragment-order image), gathers its eight fp32 sources (L2-resident:
-        // every byte of the 47 MB of parameters is used by some thread) and writes once, coalesced.  The element-wise loop below
-        // wrote 2 bytes per lane to scattered addresses (130 us per step for all parameters; this: ~35 us).
-        const int inner = (fwd ? ci : j.co) / 8, outer = fwd ? j.co : ci;
-        const int chunks = outer * taps * inner;
-        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += gridDim.x * blockDim.x) {
-            const int k8 = i % inner, q = i / inner, t = q % taps, r = q / taps;       // r: destination row's source index (o fwd, c bwd)
-            const int row = j.row_off + r, col = j.k_off + 8 * k8, tap = fwd ? t : taps - 1 - t;
-            if (row < 0 || col < 0 || col + 8 > j.cin_pad || (rl > 0 && row >= rl)) continue;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int o = fwd ? r : 8 * k8 + e, c = fwd ? 8 * k8 + e : r;
-                v[e] = j.src[(o * ci + c) * taps + t];
+    if (sizeof(T) == 2 && j.mode != 2 && (fwd ? ci : j.co) % 8 == 0 && (j.k_off & 7) == 0 && (j.cin_pad & 7) == 0 && taps <= 25) {
+        // 16-bit weights whose packed K index runs over a multiple of 8 source channels.  The source is [o][c][tap] (tap fastest),
+        // the packed images want eight consecutive K elements (input channels of one (row, tap) in the forward layouts, output
+        // channels in the transposed ones) as one 16-byte chunk: a workgroup stages a tile of 8 (o) x 32 (c) x taps fp32 weights in LDS
+        // with coalesced loads (each o row of the tile is 32 * taps contiguous floats), then every thread assembles whole chunks from
+        // LDS and stores them coalesced -- no scattered 2-byte stores (the element-wise loop below: 130 us per step for all
+        // parameters) and no strided 4-byte gathers from global memory.
+        __shared__ float tile[8][32 * 25];
+        const int ot = (j.co + 7) / 8, ctn = (ci + 31) / 32, ntiles = ot * ctn, row_f = 32 * taps;
+        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+            const int o0 = (tl / ctn) * 8, c0 = (tl % ctn) * 32;
+            const int cw = min(32, ci - c0), ow = min(8, j.co - o0);                 // valid extent of this tile
+            __syncthreads();
+            for (int e = threadIdx.x; e < 8 * row_f; e += blockDim.x) {
+                const int r = e / row_f, f = e - r * row_f;
+                tile[r][f] = (r < ow && f < cw * taps) ? j.src[((o0 + r) * ci + c0) * taps + f] : 0.f;
             }
-            u32x4 raw;
-            T* e8 = (T*)&raw;
+            __syncthreads();
+            // forward layouts: chunk = (o, tap, 8 c);  transposed: chunk = (c, tap, 8 o)
+            const int nch = fwd ? 8 * taps * 4 : 32 * taps;
+            for (int q = threadIdx.x; q < nch; q += blockDim.x) {
+                int row, col, tap;
+                float v[8];
+                if (fwd) {
+                    const int k8 = q & 3, t = (q >> 2) % taps, r = (q >> 2) / taps;
+                    if (r >= ow || 8 * k8 >= cw) continue;
+                    row = j.row_off + o0 + r; col = j.k_off + c0 + 8 * k8; tap = t;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) e8[e] = from_f32<T>(v[e]);
-            const long long di = j.mode >= 4 ? (long long)dbx_frag_index(row, tap, col, j.cin_pad, (int)j.ktot, taps)
-                                             : (long long)row * j.ktot + (long long)tap * j.cin_pad + col;
-            *(u32x4*)(wp + di) = raw;
+                    for (int e = 0; e < 8; ++e) v[e] = tile[r][(8 * k8 + e) * taps + t];
+                } else {
+                    const int c = q % 32, t = q / 32;
+                    if (c >= cw) continue;
+                    row = j.row_off + c0 + c; col = j.k_off + o0; tap = taps - 1 - t;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = tile[e][c * taps + t];
+                }
+                if (row < 0 || col < 0 || col + 8 > j.cin_pad || (rl > 0 && row >= rl)) continue;
+                u32x4 raw;
+                T* e8 = (T*)&raw;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) e8[e] = from_f32<T>(v[e]);
+                const long long di = j.mode >= 4 ? (long long)dbx_frag_index(row, tap, col, j.cin_pad, (int)j.ktot, taps)
+                                                 : (long long)row * j.ktot + (long long)tap * j.cin_pad + col;
+                *(u32x4*)(wp + di) = raw;
+            }
         }
         return;
     }
