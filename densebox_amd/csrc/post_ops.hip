@@ -86,7 +86,8 @@ __device__ __forceinline__ void block_argmax_cached(float bv, int bi, float* red
 // greedy NMS over dets[n][dc] (float64): keep list in `keep` (keep[0] = count).  order = score descending, ties by
 // higher row index first (= numpy argsort(stable)[::-1]; DenseBox.py:3415).
 #define NMS_LDS_MAX 1024
-__device__ void nms_block(const double* dets, int n, int dc, double thresh, int* keep, int* order, unsigned char* supp) {
+__device__ void nms_block(const double* dets, int n, int dc, double thresh, int* keep, int* order, unsigned char* supp,
+                          unsigned long long* mask = nullptr) {
     const int tid = threadIdx.x, nt = blockDim.x;
     // (NaN scores compare false both ways: the ranks below are then not a permutation -- a diverged network must give a strange
     // order, never an out-of-range row index: every slot starts as a valid row)
@@ -114,6 +115,56 @@ __device__ void nms_block(const double* dets, int n, int dc, double thresh, int*
             sp[q] = 0;
         }
         __syncthreads();
+        if (mask != nullptr && n > 64) {
+            // Many boxes (K = 1000): the greedy loop above costs one barrier per surviving box (~0.6 ms).  Instead (1) every thread
+            // fills one row of the suppression matrix -- bit q of row p (q > p, rank order): box p would suppress box q, with the
+            // very same fp64 expression -- into `mask` (n x 16 words, global scratch), all pairs in parallel; (2) ONE wave walks the
+            // rows in rank order with the removed-set in registers (lane w holds word w), rows fetched 32 at a time.
+            const int nw = (n + 63) >> 6;
+            for (int p_ = tid; p_ < n; p_ += nt) {
+                const double x1 = bx1[p_], y1 = by1[p_], x2 = bx2[p_], y2 = by2[p_], ai = bar[p_];
+                for (int w = 0; w < nw; ++w) {
+                    unsigned long long bits = 0ull;
+                    if (64 * w + 63 > p_) {
+                        for (int b = 0; b < 64; ++b) {
+                            const int q = 64 * w + b;
+                            if (q <= p_ || q >= n) continue;
+                            const double xx1 = fmax(x1, bx1[q]), yy1 = fmax(y1, by1[q]), xx2 = fmin(x2, bx2[q]), yy2 = fmin(y2, by2[q]);
+                            const double ww = fmax(0.0, xx2 - xx1 + 1), hh = fmax(0.0, yy2 - yy1 + 1);
+                            const double inter = ww * hh;
+                            const double ovr = inter / (ai + bar[q] - inter);
+                            if (!(ovr <= thresh)) bits |= 1ull << b;             // NaN is dropped, like np.where(ovr <= t)
+                        }
+                    }
+                    mask[(size_t)p_ * 16 + w] = bits;
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (tid < 64) {
+                const int lane = tid;
+                unsigned long long removed = 0ull;                  // lanes >= nw carry nothing
+                int cnt = 0;
+                for (int p0 = 0; p0 < n; p0 += 32) {
+                    unsigned long long rows[32];
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) rows[r] = (lane < nw && p0 + r < n) ? mask[(size_t)(p0 + r) * 16 + lane] : 0ull;
+#pragma unroll
+                    for (int r = 0; r < 32; ++r) {
+                        const int pos = p0 + r;
+                        if (pos >= n) break;
+                        const unsigned long long word = __shfl(removed, pos >> 6);
+                        if (!((word >> (pos & 63)) & 1ull)) {          // (uniform) box `pos` survives
+                            if (lane == 0) keep[1 + cnt] = order[pos];
+                            ++cnt;
+                            removed |= rows[r];
+                        }
+                    }
+                }
+                if (lane == 0) keep[0] = cnt;
+            }
+            return;
+        }
         int cnt = 0;
         for (int pos = 0; pos < n; ++pos) {
             if (sp[pos]) continue;                              // uniform: sp[] only changes between barriers
@@ -160,7 +211,7 @@ __device__ void nms_block(const double* dets, int n, int dc, double thresh, int*
 struct DetArgs {
     const float* score; const float* loc; const float* lm_heat; const float* lm_loc;
     int rows, cols, K, dc; double thresh;
-    double* dets; long long* topk; int* keep; float* work; int* order; unsigned char* supp;
+    double* dets; long long* topk; int* keep; float* work; int* order; unsigned char* supp; unsigned long long* mask;
 };
 
 // order-preserving key of a score for the radix select: larger float <-> larger key, -0 == +0, NaN below every number
@@ -263,7 +314,12 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
         if (tid < a.K) a.topk[tid] = (long long)(~(unsigned)(cand[tid] & 0xffffffffull));
         __syncthreads();
     } else {
-        for (int i = tid; i < n; i += DET_THREADS) a.work[i] = a.score[i];
+        // the retire-and-rescan rounds go through a working copy of the scores: in LDS when the map fits (<= 128 x 128, the 512 x 512
+        // input: a round's store -> 64 reloads of the winner's bucket is an LDS round trip instead of an L2 one), else in global scratch
+        constexpr int WORK_LDS = 16384;
+        __shared__ float work_lds[WORK_LDS];
+        float* const work = n <= WORK_LDS ? work_lds : a.work;
+        for (int i = tid; i < n; i += DET_THREADS) work[i] = a.score[i];
         __syncthreads();
         // K rounds of arg-max over a two-level structure: LDS holds the (max, arg-max) of every bucket of 64 consecutive scores;
         // a round reduces the bucket maxima (LDS only) and one wave re-scans the winner's bucket (64 loads in flight at once),
@@ -274,7 +330,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
         const bool two_level = nb <= NB_MAX;
         auto scan_bucket = [&](int b) {                              // one wave: arg-max of bucket b -> LDS
             const int i = b * BK + lane;
-            float v = i < n ? a.work[i] : -INFINITY; int vi = i < n ? i : 0x7fffffff;
+            float v = i < n ? work[i] : -INFINITY; int vi = i < n ? i : 0x7fffffff;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const float v2 = __shfl_down(v, off); const int i2 = __shfl_down(vi, off);
@@ -290,7 +346,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
         auto rescan = [&]() {                                        // fallback for huge maps: per-thread cached candidate
             bv = -INFINITY; bi = 0x7fffffff;
             for (int i = tid; i < n; i += DET_THREADS) {
-                const float v = a.work[i];
+                const float v = work[i];
                 if (v > bv || bi == 0x7fffffff) { bv = v; bi = i; }
             }
         };
@@ -305,14 +361,14 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
                 }
                 block_argmax_cached(cv, ci, red_v, red_i, v, idx);
                 if (wv == 0) {                                       // wave 0 retires the winner and refreshes its bucket
-                    if (lane == 0) a.work[idx] = -INFINITY;
+                    if (lane == 0) work[idx] = -INFINITY;
                     __builtin_amdgcn_wave_barrier();
                     __threadfence_block();
                     scan_bucket(idx / BK);
                 }
             } else {
                 block_argmax_cached(bv, bi, red_v, red_i, v, idx);
-                if ((idx & (DET_THREADS - 1)) == tid) { a.work[idx] = -INFINITY; rescan(); }
+                if ((idx & (DET_THREADS - 1)) == tid) { work[idx] = -INFINITY; rescan(); }
             }
             if (tid == 0) a.topk[k] = idx;
             __syncthreads();
@@ -345,11 +401,12 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
     }
     __threadfence_block();
     __syncthreads();
-    nms_block(a.dets, a.K, a.dc, a.thresh, a.keep, a.order, a.supp);
+    nms_block(a.dets, a.K, a.dc, a.thresh, a.keep, a.order, a.supp, a.mask);
 }
 
 extern "C" int64_t dbx_detect_scratch_bytes(int32_t rows, int32_t cols, int32_t K) {
-    return (int64_t)rows * cols * 4 + (int64_t)K * 4 + (int64_t)K + 256;
+    // scores copy, NMS order, suppression flags, + the 16-word-per-box suppression matrix when the boxes fit the LDS path
+    return (int64_t)rows * cols * 4 + (int64_t)K * 4 + ((int64_t)K + 255) / 256 * 256 + (K <= NMS_LDS_MAX ? (int64_t)K * 128 : 0) + 256;
 }
 
 extern "C" int dbx_detect(const float* score, const float* loc, const float* lm_heat, const float* lm_loc, int32_t rows,
@@ -365,7 +422,9 @@ extern "C" int dbx_detect(const float* score, const float* loc, const float* lm_
     char* s = (char*)scratch;
     a.work = (float*)s; s += (size_t)rows * cols * 4;
     a.order = (int*)s; s += (size_t)K * 4;
-    a.supp = (unsigned char*)s;
+    a.supp = (unsigned char*)s; s += ((size_t)K + 255) / 256 * 256;
+    s = (char*)(((size_t)s + 7) & ~(size_t)7);                          // (inside the 256 spare bytes)
+    a.mask = K <= NMS_LDS_MAX ? (unsigned long long*)s : nullptr;
     hipLaunchKernelGGL(detect_kernel, dim3(1), dim3(DET_THREADS), 0, (hipStream_t)stream, a);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
