@@ -1,12 +1,13 @@
 #!/bin/bash
 # usage: tools/collect_profiles.sh <tag> [dtype]  -- everything the bench line's roofline object cites, into gpurun_out/:
 #   <tag>_kernel_stats.txt   rocprofv3 --kernel-trace per-kernel durations of the bench command
-#   <tag>_mfma_busy.txt      cycle / MFMA-busy counters per conv / wgrad kernel (own --pmc pass)
+#   <tag>_mfma_busy.txt      cycle / MFMA-busy / wait counters per kernel (own --pmc pass)
 #   <tag>_pmc_traffic.json   HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (own --pmc passes), stamped with the source hash
 #   <tag>_timeline.txt       kernel sequence of one step
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 tag=$1; dt=${2:-f16}
+mkdir -p $(dirname $R/gpurun_out/$tag)
 B="python $R/bench.py --dtype $dt --no-cpu-baseline --no-inference"
 rm -rf /tmp/cp_*
 rocprofv3 --kernel-trace -d /tmp/cp_kt -o k -- $B --steps 10 --warmup 5 > /tmp/cp_kt.log 2>&1
