@@ -287,6 +287,11 @@ def main():
         dt = float(t.item())
     loss_val = float(loss.detach())
     assert np.isfinite(loss_val), 'training step produced a non-finite loss'
+    # 16-bit training runs without loss scaling (the reference loss is an un-normalised sum: the risk is overflow of the f16
+    # activation gradients, not underflow): every parameter gradient of the last timed step must be finite (outside the timed region)
+    gflat = dp.reducer.flat
+    assert bool(torch.isfinite(gflat).all()), 'non-finite parameter gradient in %s training' % args.dtype
+    grad_absmax = float(gflat.abs().max())
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream: 3 extra, untimed steps.
     # EVERY rank runs them (they contain collectives); only rank 0 records events.
@@ -345,7 +350,8 @@ def main():
             'config': {'workload': 'full training step (fwd + fused dense loss w/ hard-negative mining + bwd + grad '
                                    'all-reduce + SGD) of %s on 240x240 patches' % kind,
                        'net': kind, 'batch_per_gpu': n, 'global_batch': n * world, 'patch': '240x240',
-                       'parallelism': 'dp%d' % world, 'half_neg': half, 'loss': round(loss_val, 2)},
+                       'parallelism': 'dp%d' % world, 'half_neg': half, 'loss': round(loss_val, 2),
+                       'grad_finite': True, 'grad_absmax': round(grad_absmax, 3)},
             'step_tflops_per_gpu': round(n * STEP_GFLOP[kind] / (ms * 1e-3) / 1e3, 1),
             'roofline': roof,
             # the live process group the gradient all-reduce ran on ("nccl" is RCCL on ROCm): lets a scaling run be checked for
