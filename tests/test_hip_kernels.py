@@ -558,3 +558,62 @@ def test_upsample_bilinear_forward_backward(shape, dtn):
             gref = gref * (gate.to(tdt).float() > 0)
         gotd = tdx[:, 1:1 + hi, 1:1 + wi].permute(0, 3, 1, 2).float()
         assert torch.allclose(gotd, gref, rtol=tol, atol=tol * (1 + gref.abs().max().item())), (gotd - gref).abs().max().item()
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+def test_pack_multi_equals_pack_weight_all_layouts(dtn):
+    """dbx_pack_multi (one launch for a table of jobs; LDS-tile path for 16-bit weights, element-wise path otherwise) writes exactly
+    what dbx_pack_weight writes, for the plain and fragment-order images of both orientations, side-by-side placement and the
+    negative offsets that cut a channel range out of a wider tensor."""
+    L = _lib.lib()
+    dt = _lib.DTYPE_ID[dtn]
+    es = 2
+    g = torch.Generator(device='cpu').manual_seed(3)
+    # (co, ci, k, mode, rows_pad, cin_pad, row_off, k_off)
+    cases = [(256, 128, 3, 0, 256, 128, 0, 0), (256, 128, 3, 1, 128, 256, 0, 0), (256, 128, 3, 4, 256, 128, 0, 0), (256, 128, 3, 5, 128, 256, 0, 0),
+             (512, 768, 1, 4, 1024, 768, 512, 0), (512, 768, 1, 5, 512, 1024, 0, 512), (512, 768, 1, 1, 256, 1024, -512, 512),
+             (512, 768, 1, 5, 256, 1024, -512, 0), (64, 64, 5, 0, 64, 64, 0, 0), (64, 3, 3, 0, 64, 8, 0, 0), (4, 512, 1, 0, 64, 2048, 1, 512),
+             (1, 64, 1, 1, 64, 8, 0, 0)]
+    jobs, refs, outs, keep = [], [], [], []
+    for co, ci, k, mode, rows_pad, cin_pad, row_off, k_off in cases:
+        w = torch.randn(co, ci, k, k, generator=g).cuda()
+        d = ConvDesc(dt, k, k, 0, cin_pad, rows_pad, 0)
+        elems = L.dbx_conv_packed_elems(C.byref(d))
+        ref = torch.zeros(elems * es, dtype=torch.uint8, device='cuda')
+        out = torch.zeros_like(ref)
+        check(L.dbx_pack_weight(dt, mode, ptr(w), co, ci, k, k, ptr(ref), rows_pad, cin_pad, row_off, k_off, stream_ptr()))
+        ktot = (k * k * cin_pad * es + 127) // 128 * 128 // es
+        jobs.append((w.data_ptr(), out.data_ptr(), co, ci, k * k, mode, rows_pad if mode >= 4 else ktot, cin_pad, row_off, k_off, rows_pad))
+        refs.append(ref); outs.append(out); keep.append(w)
+    rec = np.zeros(len(jobs), dtype=[('src', '<u8'), ('dst', '<u8'), ('co', '<i4'), ('ci', '<i4'), ('taps', '<i4'), ('mode', '<i4'),
+                                     ('ktot', '<i8'), ('cin_pad', '<i4'), ('row_off', '<i4'), ('k_off', '<i4'), ('rows_lim', '<i4')])
+    for i, j in enumerate(jobs):
+        rec[i] = j
+    tab = torch.from_numpy(rec.view(np.uint8).copy()).cuda()
+    check(L.dbx_pack_multi(dt, ptr(tab), len(jobs), max(j[2] * j[3] * j[4] for j in jobs), stream_ptr()))
+    torch.cuda.synchronize()
+    for case, ref, out in zip(cases, refs, outs):
+        assert torch.equal(ref, out), case
+        assert int(ref.view(torch.int16).ne(0).sum()) > 0, case
+
+
+@pytest.mark.parametrize('dtn', ['bf16', 'f16'])
+def test_conv_wgrad_slice_writes_a_column_range(dtn):
+    """dbx_conv_wgrad_slice: the gradient of one tensor of a channel concat lands in its column range of the wider OIHW gradient,
+    bit-identical to dbx_conv_wgrad of that tensor alone, and leaves the other columns alone."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    n, h, w, ci, co, ctot, coff = 3, 30, 30, 256, 512, 768, 512
+    g = torch.Generator(device='cpu').manual_seed(11)
+    x = torch.randn(n, ci, h, w, generator=g).cuda()
+    dz = torch.randn(n, co, h, w, generator=g).cuda()
+    fx, tx, xv = framed(x, 1, tdt)
+    fz, tz, dzv = framed(dz, 1, tdt)
+    sc = torch.empty(L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dzv), C.byref(xv), 1, 1), dtype=torch.uint8, device='cuda')
+    dw = torch.empty(co, ci, 1, 1, device='cuda'); db = torch.empty(co, device='cuda')
+    check(L.dbx_conv_wgrad(dt, C.byref(dzv), C.byref(xv), 1, 1, 0, co, ci, ptr(dw), ptr(db), ptr(sc), 0, stream_ptr()))
+    wide = torch.full((co, ctot, 1, 1), 7.0, device='cuda'); db2 = torch.empty(co, device='cuda')
+    check(L.dbx_conv_wgrad_slice(dt, C.byref(dzv), C.byref(xv), 1, 1, 0, co, ci, ptr(wide), ctot, coff, ptr(db2), ptr(sc), 0, stream_ptr()))
+    assert torch.equal(wide[:, coff:coff + ci], dw) and torch.equal(db, db2)
+    assert float((wide[:, :coff] - 7.0).abs().max()) == 0.0
+    assert L.dbx_conv_wgrad_slice(dt, C.byref(dzv), C.byref(xv), 1, 1, 0, co, ci, ptr(wide), ctot, coff + 1, ptr(db2), ptr(sc), 0, stream_ptr()) != 0
