@@ -70,6 +70,7 @@ SIGNATURES = {
     'dbx_conv_dgrad_wgrad1': (C.c_int, [_PC, _PV, _VP, _PV, _PV, _I32, _VP, _VP, _VP, _I32, _VP]),
     'dbx_conv_pool_fusable': (C.c_int, [_PC, _PV, _PV]),
     'dbx_conv_forward_pool': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _I32, _VP]),
+    'dbx_conv_forward_pool_idx': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _I32, _VP, _VP]),
     'dbx_pack_weight': (C.c_int, [_I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
     'dbx_fold_heads': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP]),
     'dbx_pack_multi': (C.c_int, [_I32, _VP, _I32, _I64, _VP]),
@@ -91,6 +92,9 @@ SIGNATURES = {
     'dbx_framed_add_ch': (C.c_int, [_I32, _PV, _I32, _I32, _PV, _I32, _VP]),
     'dbx_maxpool2x2': (C.c_int, [_I32, _PV, _PV, _VP]),
     'dbx_maxpool2x2_bwd': (C.c_int, [_I32, _PV, _PV, _PV, _I32, _I32, _VP]),
+    'dbx_maxpool_idx_bytes': (C.c_int64, [_I32, _I32, _I32, _I32]),
+    'dbx_maxpool2x2_idx': (C.c_int, [_I32, _PV, _PV, _VP, _VP]),
+    'dbx_maxpool2x2_bwd_idx': (C.c_int, [_I32, _VP, _PV, _PV, _I32, _I32, _VP]),
     'dbx_upsample_bilinear': (C.c_int, [_I32, _PV, _PV, _VP]),
     'dbx_upsample_bilinear_bwd': (C.c_int, [_I32, _PV, _PV, _PV, _VP]),
     'dbx_loss_forward_backward': (C.c_int, [C.POINTER(LossDesc), C.POINTER(LossIO), _VP, _VP]),

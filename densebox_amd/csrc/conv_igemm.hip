@@ -44,6 +44,7 @@ struct ConvArgs {
     char* y2; const char* gate2;
     int y2_hp, y2_wp, y2_ld, y2_pad, g2_hp, g2_wp, g2_ld, g2_pad;
     int split_c, epi2, cout_valid2;
+    unsigned char* pool_idx;        // fused pooling (EPI2_POOL): arg-max nibbles of the pooled map (dbx_maxpool2x2_idx layout), or null
 };
 
 // XOR mask (in 16-byte chunks) of a tile row, applied on the LDS-DMA source side and on the fragment reads.
@@ -987,6 +988,29 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a, cons
                         }
                     }
                 }
+                if (a.pool_idx) {
+                    // arg-max nibbles for dbx_maxpool2x2_bwd_idx (layout of dbx_maxpool2x2_idx: channel c in byte c / 2): window
+                    // order (0,0),(0,1),(1,0),(1,1) = (this lane, row 0), (lane ^ 1, row 0), (this lane, row 1), (lane ^ 1, row 1),
+                    // first maximum wins.  Compared in f32, before the rounding to T: where two window elements round to the same T
+                    // the gradient goes to the one the fp32 reference would pick (dbx_maxpool2x2_idx on the stored map: the first).
+                    unsigned char* ipix = a.pool_idx + ((size_t)(n * (tg.H >> 1) + (oy >> 1)) * (tg.W >> 1) + (ox >> 1)) * 32 + g * 2;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        unsigned int w16 = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float a0 = v[ni][0][j], c0 = v[ni][1][j];
+                            const float b0 = dpp_xor1(a0), d0 = dpp_xor1(c0);
+                            int arg = 0;
+                            float m = a0;
+                            if (b0 > m) { m = b0; arg = 1; }
+                            if (c0 > m) { m = c0; arg = 2; }
+                            if (d0 > m) { m = d0; arg = 3; }
+                            w16 |= (unsigned int)(arg | (m > 0.f ? 4 : 0)) << (4 * j);
+                        }
+                        if (ok && !(fr & 1)) *(unsigned short*)(ipix + ni * 8) = (unsigned short)w16;
+                    }
+                }
                 // rounding to T is monotonic: max of the f32 values, then rounded == max of the rounded values (dbx_maxpool2x2)
                 T* ppix = (T*)a.y2 + (size_t)((n * a.y2_hp + (oy >> 1) + a.y2_pad) * a.y2_wp + ((ox >> 1) + a.y2_pad)) * (size_t)a.y2_ld;
 #pragma unroll
@@ -1313,7 +1337,7 @@ template <typename T>
 static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void* w, const float* bias,
                           const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int dm_ld, hipStream_t s,
                           const dbx_view* y2 = nullptr, const dbx_view* gate2 = nullptr, int split_c = 0, int epi2 = 0,
-                          dbx_conv_plan_t* plan = nullptr) {
+                          dbx_conv_plan_t* plan = nullptr, void* pool_idx = nullptr) {
     constexpr int ES = sizeof(T);
     // One selection path for launching and for dbx_conv_plan(): with `plan` set, the chosen kernel is reported instead of launched.
     static const char* const tname = sizeof(T) == 4 ? "f32" : (DType<T>::id == DBX_F16 ? "f16" : "bf16");
@@ -1374,6 +1398,7 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.epi = d->epilogue & ~DBX_CONV_WFRAG; a.dm_ld = dm_ld; a.drop_seed = d->drop_seed;
     a.y2 = nullptr; a.gate2 = nullptr; a.split_c = 0; a.epi2 = 0; a.cout_valid2 = 0;
     a.y2_hp = a.y2_wp = a.y2_ld = a.y2_pad = a.g2_hp = a.g2_wp = a.g2_ld = a.g2_pad = 0;
+    a.pool_idx = (unsigned char*)pool_idx;
     if (y2 && (epi2 & EPI2_POOL)) {
         // pooled second destination: the 64 -> 64 halo-tile kernel only (dbx_conv_pool_fusable)
         DBX_REQUIRE(c64_pool_ok<T>(d, x, y), "conv pool: needs a 16-bit 3x3/pad 1 64 -> 64 layer on congruent frames with even H, W and a bias/ReLU epilogue");
@@ -1619,12 +1644,17 @@ extern "C" int dbx_conv_pool_fusable(const dbx_conv_desc* d, const dbx_view* x, 
         default: return 0;
     }
 }
-extern "C" int dbx_conv_forward_pool(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
-                                     const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* stream) {
+extern "C" int dbx_conv_forward_pool_idx(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
+                                         const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* idx, void* stream) {
     if (!d || !x || !y || !ypool || !w_packed) { dbx_set_error("conv pool: null argument"); return DBX_ERR_ARG; }
     if (d->dtype == DBX_F32) { dbx_set_error("conv pool: 16-bit types only"); return DBX_ERR_DTYPE; }
+    if (idx && ((size_t)idx % 4) != 0) { dbx_set_error("conv pool: idx must be 4-byte aligned"); return DBX_ERR_ARG; }
     DBX_DISPATCH_DTYPE(d->dtype, conv_forward_t, d, x, w_packed, bias, y, nullptr, nullptr, 0, (hipStream_t)stream, ypool, nullptr, 0,
-                       EPI2_POOL | (write_full ? 0 : EPI2_POOL_ONLY));
+                       EPI2_POOL | (write_full ? 0 : EPI2_POOL_ONLY), nullptr, idx);
+}
+extern "C" int dbx_conv_forward_pool(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
+                                     const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* stream) {
+    return dbx_conv_forward_pool_idx(d, x, w_packed, bias, y, ypool, write_full, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ weight packing

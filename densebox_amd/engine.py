@@ -127,6 +127,13 @@ class Plan:
         self.drop_seed = 0
         self.mask_buf = None
         self.ws = torch.zeros(off, dtype=torch.uint8, device=device)
+        # training: arg-max nibbles of the three pooling layers (dbx_maxpool2x2_idx layout, half a byte per pooled element): the
+        # pooling backward reads them instead of the un-pooled activations, and conv1_2's full-resolution output is never written
+        # (its only other reader was pool1's backward).  DBX_POOL_IDX=0 keeps the activation-reading backward (A/B, tests).
+        self.pool_idx = None
+        if train and os.environ.get('DBX_POOL_IDX', '1') != '0':
+            self.pool_idx = {k: torch.empty(n * (hh // 2) * (ww // 2) * (c // 2) + 16, dtype=torch.uint8, device=device)
+                             for k, (hh, ww, c) in {'a12': (h, w, 64), 'a22': (h2, w2, 128), 'fusion': (h4, w4, 256)}.items()}
         base = self.ws.data_ptr()
         assert base % 256 == 0
         for b in B.values():
@@ -499,6 +506,14 @@ class Engine:
                        self._bias([stem], max(64, cout)), 3, 3, 1, cin_pad, max(64, cout),
                        RELU | (_lib.CONV_WFRAG if frag else 0), alg_ci=cin)
 
+        PI = P.pool_idx
+
+        def pool(xv, yv, key):
+            if PI is not None:
+                check(L.dbx_maxpool2x2_idx(dt, C.byref(xv), C.byref(yv), ptr(PI[key]), s))
+            else:
+                check(L.dbx_maxpool2x2(dt, C.byref(xv), C.byref(yv), s))
+
         conv3('conv1_1_1', 'x0', 'a11', 3, 64)
         d12 = ConvDesc(dt, 3, 3, 1, 64, 64, RELU, 0)
         a11v, a12v, p1v = B['a11'].view(), B['a12'].view(), B['p1'].view()
@@ -508,23 +523,25 @@ class Engine:
             if prof is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            check(L.dbx_conv_forward_pool(C.byref(d12), C.byref(a11v), ptr(self._w_fwd(dt, 'conv1_2_1', 64, 64, frag=False)),
-                                          ptr(self._bias(['conv1_2_1'], 64)), C.byref(a12v), C.byref(p1v), 1 if train else 0, s))
+            # training without the nibbles (DBX_POOL_IDX=0): pool1's backward re-reads the full map, so it is written
+            check(L.dbx_conv_forward_pool_idx(C.byref(d12), C.byref(a11v), ptr(self._w_fwd(dt, 'conv1_2_1', 64, 64, frag=False)),
+                                              ptr(self._bias(['conv1_2_1'], 64)), C.byref(a12v), C.byref(p1v),
+                                              1 if (train and PI is None) else 0, ptr(PI['a12']) if PI else None, s))
             if prof is not None:
                 ev1.record()
                 prof.append({'kernel': self.conv_plan(dt, a11v, a12v, 3, 3, 1, 64, 64, RELU)[1],
                              'flops': 2.0 * a12v.n * a12v.h * a12v.w * 9 * 64 * 64, 'start': ev0, 'end': ev1})
         else:
             conv3('conv1_2_1', 'a11', 'a12', 64, 64)
-            check(L.dbx_maxpool2x2(dt, C.byref(a12v), C.byref(p1v), s))
+            pool(a12v, p1v, 'a12')
         conv3('conv2_1_1', 'p1', 'a21', 64, 128)
         conv3('conv2_2_1', 'a21', 'a22', 128, 128)
-        check(L.dbx_maxpool2x2(dt, C.byref(B['a22'].view()), C.byref(B['p2'].view()), s))
+        pool(B['a22'].view(), B['p2'].view(), 'a22')
         conv3('conv3_1_1', 'p2', 'a31', 128, 256)
         conv3('conv3_2_1', 'a31', 'a32', 256, 256)
         c34 = B['fusion'].view(512, 256)
         conv3('conv3_4_1', 'a32', None, 256, 256, dst_view=c34)       # writes fusion[:, 512:768]
-        check(L.dbx_maxpool2x2(dt, C.byref(c34), C.byref(B['p3'].view()), s))
+        pool(c34, B['p3'].view(), 'fusion')
         conv3('conv4_1_1', 'p3', 'a41', 256, 512)
         conv3('conv4_2_1', 'a41', 'a42', 512, 512)
         conv3('conv4_3_1', 'a42', 'a43', 512, 512)
@@ -921,6 +938,10 @@ class Engine:
                     continue
             if item[0] == 'pool':
                 _, xname, dyname, dxname, acc = item
+                if P.pool_idx is not None:
+                    check(L.dbx_maxpool2x2_bwd_idx(dt, ptr(P.pool_idx[xname]), C.byref(B[dyname].view()), C.byref(B[dxname].view()),
+                                                   acc, 1, s))
+                    continue
                 xv = c34 if xname == 'fusion' else B[xname].view()
                 check(L.dbx_maxpool2x2_bwd(dt, C.byref(xv), C.byref(B[dyname].view()), C.byref(B[dxname].view()),
                                            acc, 1, s))

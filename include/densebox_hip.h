@@ -112,6 +112,13 @@ int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x, const void
 int dbx_conv_pool_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y);
 int dbx_conv_forward_pool(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
                           const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* stream);
+/* ... and the arg-max nibbles of the pooled map in `idx` (layout of dbx_maxpool2x2_idx; null: not written).  With them a training
+ * step needs the full-resolution conv1_2 output for nothing -- its only other reader was the pooling backward -- so write_full = 0
+ * saves the 472 MB store (batch 64) and dbx_maxpool2x2_bwd_idx the 472 MB re-read.  The nibbles are taken from the fp32 values
+ * before they are rounded to the 16-bit type: where two window elements round to the same number the gradient goes to the one the
+ * fp32 reference picks (dbx_maxpool2x2_idx on the rounded map would pick the first of them). */
+int dbx_conv_forward_pool_idx(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
+                              const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* idx, void* stream);
 
 /* fp32 OIHW [co][ci][kh][kw] -> packed compute-dtype weight.
  * mode 0: forward            wp[co][tap][ci]            = w[co][ci][tap]
@@ -216,6 +223,16 @@ int dbx_maxpool2x2(int32_t dtype, const dbx_view* x, const dbx_view* y, void* st
 /* x = pre-pool activation, dy = grad of the pooled map, dx = grad of the pre-pool map (same frame as x) */
 int dbx_maxpool2x2_bwd(int32_t dtype, const dbx_view* x, const dbx_view* dy, const dbx_view* dx,
                        int32_t accumulate, int32_t relu_gate, void* stream);
+/* Training: the forward pooling also records WHERE each maximum came from, so that the backward pass reads the pooled gradient and
+ * half a byte per pooled element instead of the whole un-pooled activation (nn.MaxPool2d backward, DenseBox.py:187 / :191 / :204
+ * under loss.backward(), :2186).  idx: device buffer of dbx_maxpool_idx_bytes(n, h, w, c) bytes (h, w, c of the UN-pooled map),
+ * 4-byte aligned, dense [n][h/2][w/2][c/2]: one nibble per pooled element, channel c in byte c/2 (even channel = low nibble);
+ * bits 0..1 = window position of the first maximum in (0,0),(0,1),(1,0),(1,1) order (ATen's tie rule), bit 2 = (maximum > 0).
+ * dbx_maxpool2x2_bwd_idx gives exactly dbx_maxpool2x2_bwd's result for the map the nibbles were taken from; relu_gate uses bit 2. */
+int64_t dbx_maxpool_idx_bytes(int32_t n, int32_t h, int32_t w, int32_t c);
+int dbx_maxpool2x2_idx(int32_t dtype, const dbx_view* x, const dbx_view* y, void* idx, void* stream);
+int dbx_maxpool2x2_bwd_idx(int32_t dtype, const void* idx, const dbx_view* dy, const dbx_view* dx,
+                           int32_t accumulate, int32_t relu_gate, void* stream);
 int dbx_upsample_bilinear(int32_t dtype, const dbx_view* x, const dbx_view* y, void* stream);
 /* gate (optional): forward activation of dx's tensor; dx is zeroed where gate <= 0 (ReLU backward) */
 int dbx_upsample_bilinear_bwd(int32_t dtype, const dbx_view* dy, const dbx_view* dx, const dbx_view* gate, void* stream);

@@ -467,9 +467,76 @@ def test_conv_forward_pool_equals_conv_then_maxpool(shape, dtn):
     check(L.dbx_conv_forward_pool(C.byref(d), C.byref(xv), ptr(wp), ptr(b), C.byref(yv3), C.byref(pv3), 0, stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(fp2, fp3) and float(fy3.float().abs().sum()) == 0
+    # ... with the arg-max nibbles (training): same pooled map, the full map not needed; the pooling backward driven by them equals
+    # the activation-reading backward on the full map, except where two window elements round to the same 16-bit value (the
+    # fused kernel compares before rounding): there the gradient sits on another element of the same window with an EQUAL activation
+    idx = torch.zeros(L.dbx_maxpool_idx_bytes(n, h, w, 64) + 16, dtype=torch.uint8, device='cuda')
+    fy5, ty5, yv5 = framed(torch.zeros(n, 64, h, w), 1, tdt)
+    fp5, tp5, pv5 = framed(torch.zeros(n, 64, h // 2, w // 2), 1, tdt)
+    check(L.dbx_conv_forward_pool_idx(C.byref(d), C.byref(xv), ptr(wp), ptr(b), C.byref(yv5), C.byref(pv5), 0, ptr(idx), stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(fp2, fp5) and float(fy5.float().abs().sum()) == 0 and int(idx[-16:].sum()) == 0
+    dy = torch.randn(n, 64, h // 2, w // 2, generator=g).cuda()
+    fdy, tdy, dyv = framed(dy, 0, tdt)
+    fa, ta, dxa = framed(torch.zeros(n, 64, h, w), 1, tdt)
+    fb, tb, dxb = framed(torch.zeros(n, 64, h, w), 1, tdt)
+    check(L.dbx_maxpool2x2_bwd(dt, C.byref(yv2), C.byref(dyv), C.byref(dxa), 0, 1, stream_ptr()))
+    check(L.dbx_maxpool2x2_bwd_idx(dt, ptr(idx), C.byref(dyv), C.byref(dxb), 0, 1, stream_ptr()))
+    torch.cuda.synchronize()
+    ga, gb = ta[:, 1:1 + h, 1:1 + w].float(), tb[:, 1:1 + h, 1:1 + w].float()
+    diff = ga != gb
+    assert float(diff.float().mean()) < 5e-3, float(diff.float().mean())
+    act = ty2[:, 1:1 + h, 1:1 + w].float()
+    # per window and channel: same gradient total, and where the placement differs the two chosen activations are equal
+    def win(t):
+        return t.reshape(n, h // 2, 2, w // 2, 2, 64)
+    assert torch.equal(win(ga).sum(dim=(2, 4)), win(gb).sum(dim=(2, 4)))
+    chosen_a = (win(act) * (win(ga) != 0)).sum(dim=(2, 4))
+    chosen_b = (win(act) * (win(gb) != 0)).sum(dim=(2, 4))
+    assert torch.equal(chosen_a, chosen_b)
     # odd sizes: no fused path (the caller runs conv + maxpool)
     fo, to, ov = framed(torch.zeros(n, 64, h + 1, w), 1, tdt)
     assert L.dbx_conv_pool_fusable(C.byref(d), C.byref(ov), C.byref(ov)) == 0
+
+
+@pytest.mark.parametrize('dtn', ['f32', 'bf16', 'f16'])
+@pytest.mark.parametrize('shape', [(2, 64, 12, 20), (1, 128, 15, 9), (3, 8, 6, 7), (2, 256, 60, 60)])
+def test_maxpool_idx_backward_equals_activation_backward_and_aten(shape, dtn):
+    """dbx_maxpool2x2_idx / dbx_maxpool2x2_bwd_idx (training: the backward reads arg-max nibbles instead of the un-pooled map) against
+    dbx_maxpool2x2 / dbx_maxpool2x2_bwd (bitwise, with and without accumulation and ReLU gate) and against ATen's max_pool2d backward
+    on the CPU (first maximum wins) -- on activations quantised to a few levels so that ties and all-zero windows are everywhere;
+    odd heights / widths (floor mode: the ragged row / column gets no gradient)."""
+    n, c, h, w = shape
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    g = torch.Generator(device='cpu').manual_seed(n * c + h)
+    x = F.relu(torch.round(torch.randn(n, c, h, w, generator=g) * 2) / 2)
+    dy = torch.round(torch.randn(n, c, h // 2, w // 2, generator=g) * 8) / 8
+    fx, tx, xv = framed(x.cuda(), 1, tdt)
+    fpa, tpa, pva = framed(torch.zeros(n, c, h // 2, w // 2), 1, tdt)
+    fpb, tpb, pvb = framed(torch.zeros(n, c, h // 2, w // 2), 1, tdt)
+    nb = L.dbx_maxpool_idx_bytes(n, h, w, c)
+    assert nb == n * (h // 2) * (w // 2) * (c // 2)
+    idx = torch.full((nb + 16,), 0xAB, dtype=torch.uint8, device='cuda')
+    check(L.dbx_maxpool2x2(dt, C.byref(xv), C.byref(pva), stream_ptr()))
+    check(L.dbx_maxpool2x2_idx(dt, C.byref(xv), C.byref(pvb), ptr(idx), stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(fpa, fpb) and bool((idx[nb:] == 0xAB).all())
+    fdy, tdy, dyv = framed(dy.cuda(), 0, tdt)
+    xc = x.clone().requires_grad_(True)
+    pooled = F.max_pool2d(xc, 2)
+    for acc in (0, 1):
+        for gate in (0, 1):
+            init = (torch.round(torch.randn(n, c, h, w, generator=g) * 4) / 4) if acc else torch.zeros(n, c, h, w)
+            fa, ta, dxa = framed(init.cuda(), 1, tdt)
+            fb, tb, dxb = framed(init.cuda(), 1, tdt)
+            check(L.dbx_maxpool2x2_bwd(dt, C.byref(xv), C.byref(dyv), C.byref(dxa), acc, gate, stream_ptr()))
+            check(L.dbx_maxpool2x2_bwd_idx(dt, ptr(idx), C.byref(dyv), C.byref(dxb), acc, gate, stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(fa, fb), (acc, gate)
+            gref, = torch.autograd.grad(pooled, xc, dy * (pooled > 0).float() if gate else dy, retain_graph=True)
+            got = tb[:, 1:1 + h, 1:1 + w].permute(0, 3, 1, 2).float().cpu()
+            assert torch.equal(got, gref + init), (acc, gate)       # every value is exactly representable in the 16-bit types
 
 
 @pytest.mark.parametrize('dtn', ['bf16', 'f16'])
