@@ -114,9 +114,9 @@ int dbx_conv_forward_pool(const dbx_conv_desc* d, const dbx_view* x, const void*
                           const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* stream);
 /* ... and the arg-max nibbles of the pooled map in `idx` (layout of dbx_maxpool2x2_idx; null: not written).  With them a training
  * step needs the full-resolution conv1_2 output for nothing -- its only other reader was the pooling backward -- so write_full = 0
- * saves the 472 MB store (batch 64) and dbx_maxpool2x2_bwd_idx the 472 MB re-read.  The nibbles are taken from the fp32 values
- * before they are rounded to the 16-bit type: where two window elements round to the same number the gradient goes to the one the
- * fp32 reference picks (dbx_maxpool2x2_idx on the rounded map would pick the first of them). */
+ * saves the 472 MB store (batch 64) and dbx_maxpool2x2_bwd_idx the 472 MB re-read.  With a ReLU epilogue (conv1_2) the nibbles are
+ * bitwise those dbx_maxpool2x2_idx takes from the full map (window logic on the rounded values); without one they are taken from
+ * the fp32 values before rounding (two window elements that round to the same number: the one the fp32 computation picks). */
 int dbx_conv_forward_pool_idx(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
                               const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* idx, void* stream);
 

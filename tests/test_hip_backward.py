@@ -260,11 +260,9 @@ def test_eval_and_train_forward_agree_through_fused_pool(golden, monkeypatch):
 
 @pytest.mark.parametrize('dtype', ['f32', 'f16'])
 def test_pool_backward_from_argmax_nibbles_equals_activation_reading_backward(golden, dtype, monkeypatch):
-    """A training step with the arg-max nibbles (default) against DBX_POOL_IDX=0 (pooling backward re-reads the activations): same
-    loss; fp32: every gradient bitwise equal.  16-bit: pool2 / pool3 bitwise, pool1's nibbles come from the fused conv1_2 epilogue,
-    which compares before rounding (include/densebox_hip.h): where two window elements round to the same f16 number the gradient sits
-    on the other one (0.1-0.3 % of the windows), so conv1_x gradients agree to a few percent of their norm (measured 1.3 %: the same
-    order as the f16 rounding of the gradients themselves); everything else is bitwise equal."""
+    """A training step with the arg-max nibbles (default) against DBX_POOL_IDX=0 (pooling backward re-reads the activations, conv1_2
+    writes its full-resolution map): same loss, every gradient bitwise equal -- the nibbles of the fused conv1_2 + pool1 kernel are
+    taken from the rounded values, exactly what the stored map would give."""
     g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', dtype)
 
     def grads(flag):
@@ -279,8 +277,4 @@ def test_pool_backward_from_argmax_nibbles_equals_activation_reading_backward(go
     lb, gb = grads('0')
     assert la == lb and set(ga) == set(gb)
     for k in ga:
-        if dtype != 'f32' and k.startswith('conv1_'):
-            rel = float((ga[k].double() - gb[k].double()).norm() / (gb[k].double().norm() + 1e-30))
-            assert rel <= 3e-2, (k, rel)
-        else:
-            assert torch.equal(ga[k], gb[k]), k
+        assert torch.equal(ga[k], gb[k]), k
