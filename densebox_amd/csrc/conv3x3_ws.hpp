@@ -341,19 +341,41 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
             int oy = rem / wp, fx = rem - oy * wp;
             const int H = t.hwp / wp;
             const int Wo = wp - 2 * t.xpad;
+            // ReLU gate (data gradients): the four 16-byte gate chunks of a pixel fragment are fetched PD fragments ahead of their use
+            // -- with one wave per SIMD a load issued and consumed inside one fragment's code exposes its whole latency, eight
+            // times per tile (the gated launches ran 10 % behind the un-gated ones); a second pixel walker runs ahead of the stores
+            constexpr int PD = 4;
+            u32x4 gring[PD][2][2];
+            int g_qq = qq, g_n = n, g_oy = oy, g_fx = fx;
+            auto gate_fetch = [&](u32x4 (&dst)[2][2]) {
+                const bool okg = g_qq < t.qtot && g_fx >= t.xpad && g_fx < wp - t.xpad;
+                if (okg) {
+                    const T* gpix = (const T*)gbase + (size_t)((g_n * g_hp + g_oy + g_pad) * g_wp + (g_fx - t.xpad + g_pad)) * (size_t)g_ld + cy + 8 * h;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int jp = 0; jp < 2; ++jp) dst[ni][jp] = *(const u32x4*)(gpix + ni * 32 + 16 * jp);
+                }
+                g_qq += 32;
+                if (wp >= 32) {
+                    g_fx += 32;
+                    if (g_fx >= wp) { g_fx -= wp; if (++g_oy == H) { g_oy = 0; ++g_n; } }
+                } else {
+                    g_n = g_qq / t.hwp;
+                    const int rr = g_qq - g_n * t.hwp;
+                    g_oy = rr / wp; g_fx = rr - g_oy * wp;
+                }
+            };
+            if (EPIK == 0 && (epi & DBX_EPI_GATE)) {
+#pragma unroll
+                for (int d = 0; d < PD && d < NF; ++d) gate_fetch(gring[d]);
+            }
 #pragma unroll
             for (int mi = 0; mi < NF; ++mi) {
                 const bool ok = qq < t.qtot && fx >= t.xpad && fx < wp - t.xpad;
                 const int ox = fx - t.xpad;
                 T* ypix = (T*)ybase + (size_t)((n * y_hp + oy + y_pad) * y_wp + (ox + y_pad)) * (size_t)y_ld + cy + 8 * h;
-                u32x4 gt[2][2];
-                if ((epi & DBX_EPI_GATE) && ok) {
-                    const T* gpix = (const T*)gbase + (size_t)((n * g_hp + oy + g_pad) * g_wp + (ox + g_pad)) * (size_t)g_ld + cy + 8 * h;
-#pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                        for (int jp = 0; jp < 2; ++jp) gt[ni][jp] = *(const u32x4*)(gpix + ni * 32 + 16 * jp);
-                }
+                u32x4 (&gt)[2][2] = gring[mi % PD];
                 const unsigned mpix = (unsigned)((n * H + oy) * Wo + ox);   // output pixel index (dropout counter)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
@@ -410,6 +432,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                         }
                     }
                 }
+                if (EPIK == 0 && (epi & DBX_EPI_GATE) && mi + PD < NF) gate_fetch(gring[mi % PD]);
                 __builtin_amdgcn_sched_barrier(0);                      // one fragment at a time: bounds the live accumulator copies
                 // advance 32 q': at most one row wrap (Wp >= 32) or a division
                 qq += 32;
