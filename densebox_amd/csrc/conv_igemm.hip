@@ -1506,13 +1506,19 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             if (y2 && (epi2 & DBX_EPI_GATE) && gate2) ws_ok = ws_ok && (gate2->c_off * ES) % 16 == 0 && (gate2->ld * ES) % 16 == 0;
         }
         if (wfrag) DBX_REQUIRE(ws_ok, "conv: DBX_CONV_WFRAG weights, but the problem does not qualify for the ws kernel (ask dbx_conv_plan)");
-        // Which eligible problems the plan PREFERS on it (same-box A/B inside the training step, profiles/r02_ws_vs_band.txt; round 3 after
-        // the gate prefetch of its epilogue): the kernel's fixed cost per tile (prologue, one-wave-per-SIMD epilogue with nothing to overlap
-        // it) is amortised over the K loop: it wins on the 512 -> 512 and 256 -> 256 layers, gated (data gradients: 224 vs 234 us at conv4,
-        // 246-254 vs 260-263 at conv3) or not, on 128-cout layers with >= 256 input channels, and on the 1x1 heads; the LDS band kernels
-        // keep the rest (512 -> 256 gated: 116 vs 120 us; the 128-channel layers).  A caller may still force it with DBX_CONV_WFRAG.
+        // Which eligible problems the plan PREFERS on it (same-box A/B inside the training step, profiles/r02_ws_vs_band.txt): the kernel's
+        // fixed cost per tile (prologue, one-wave-per-SIMD epilogue with nothing to overlap it) is amortised over the K loop: it wins on
+        // the un-gated 512 -> 512 and 256 -> 256 layers, on 128-cout layers with >= 256 input channels, and on the 1x1 heads; the LDS band
+        // kernels keep the rest.  Round 3 (gate chunks prefetched four fragments ahead in its epilogue): the GATED 512 -> 512 / 256 -> 256
+        // data gradients run 4-7 % faster on it in isolation (conv4: 224 vs 234-242 us, conv3: 246-256 vs 260-272) -- and the whole
+        // training step 1.2 % SLOWER (10.51 vs 10.38 ms, three alternating same-box pairs): every other MFMA kernel of the step slows
+        // by 2-3 % when these five run hotter (the part is power-managed: 1180 W, sclk 2.11 GHz average over the step), so the plan keeps
+        // the band kernel there; DBX_WS_GATED=1 prefers ws on them.  A caller may still force it with DBX_CONV_WFRAG.
+        static int ws_gated = -1;
+        if (ws_gated < 0) { const char* e = getenv("DBX_WS_GATED"); ws_gated = e ? atoi(e) : 0; }
+        const bool nogate = !(d->epilogue & DBX_EPI_GATE) || ws_gated != 0;
         const bool ws_pref = k1 || (wm == 2 && d->cin_pad >= 256) ||
-                             (wm == 1 && ((d->cin_pad >= 512 && d->cout_pad >= 512) || (d->cin_pad == 256 && d->cout_pad == 256)));
+                             (nogate && wm == 1 && ((d->cin_pad >= 512 && d->cout_pad >= 512) || (d->cin_pad == 256 && d->cout_pad == 256)));
         if (ws_ok && (wfrag || (plan && (ws_pref || ws_level() >= 2)))) {
             a.ntile_n = ctot / (256 / wm);
             if (k1 && !y2 && (a.epi & ~DBX_EPI_ACCUM) == (DBX_EPI_BIAS | DBX_EPI_DROPHASH) && ws_level() != 3)      // heads forward: fixed epilogue
