@@ -222,6 +222,11 @@ __device__ __forceinline__ unsigned det_key(float v) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// top-K by radix select + sort from this K on; below it the arg-max rounds over the two-level LDS structure are faster (same-box
+// A/B at K = 10 on a 128 x 128 map: whole 512 x 512 detect() 0.486 ms with rounds, 0.506 ms with select + a 16-element sort).
+#ifndef DET_SELECT_MIN_K
+#define DET_SELECT_MIN_K 49
+#endif
 __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
     __shared__ float red_v[DET_THREADS / 64];
     __shared__ int red_i[DET_THREADS / 64];
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
         __syncthreads();
     }
     // ---- top-K indices into a.topk, in the reference's order: larger score first, lower index on ties
-    const bool select = a.K > 48 && a.K <= DET_THREADS;
+    const bool select = a.K >= DET_SELECT_MIN_K && a.K <= DET_THREADS;
     if (select) {
         // K in (48, 1024] (round 3: K = 1000 at 1080p took 4.7 ms as 1000 arg-max rounds): radix select of the K-th largest key
         // (four 8-bit passes, LDS histogram), compaction of the keys above it plus the lowest-index ties, bitonic sort of <= 1024
@@ -297,17 +302,20 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
                 if (det_key(a.score[i]) == T) { cand[base_slot + before] = ((unsigned long long)T << 32) | (unsigned)(~(unsigned)i); ++before; }
             __syncthreads();
         }
-        for (int i = a.K + tid; i < DET_THREADS; i += DET_THREADS) cand[i] = 0ull;       // padding sorts last
+        int P2 = 2;                                               // sort size: the power of two >= K (K = 10: 16 elements, 10 exchange steps)
+        while (P2 < a.K) P2 <<= 1;
+        for (int i = a.K + tid; i < P2; i += DET_THREADS) cand[i] = 0ull;                // padding sorts last
         __syncthreads();
-        // bitonic sort, descending, 1024 elements: one element per thread
-        for (int size = 2; size <= DET_THREADS; size <<= 1) {
+        // bitonic sort, descending, P2 <= 1024 elements: one element per thread
+        for (int size = 2; size <= P2; size <<= 1) {
             for (int stride = size >> 1; stride > 0; stride >>= 1) {
                 const int partner = tid ^ stride;
-                const unsigned long long me = cand[tid], ot = cand[partner];
+                unsigned long long me = 0, ot = 0;
+                if (tid < P2) { me = cand[tid]; ot = cand[partner]; }
                 __syncthreads();
                 const bool desc = (tid & size) == 0;                // this block sorts descending
                 const bool keep_max = (tid < partner) == desc;
-                cand[tid] = keep_max ? (me > ot ? me : ot) : (me < ot ? me : ot);
+                if (tid < P2) cand[tid] = keep_max ? (me > ot ? me : ot) : (me < ot ? me : ot);
                 __syncthreads();
             }
         }

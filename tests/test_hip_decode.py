@@ -110,8 +110,8 @@ def test_nms_and_detect_survive_nan_scores():
 
 @pytest.mark.parametrize('case', ['random', 'quantised', 'constant', 'signed_zero'])
 def test_topk_select_path_matches_rounds_and_reference_order(case):
-    """K in (48, 1024] takes the radix-select path: the ranking must be the round-based path's (K <= 48) bit for bit -- larger
-    score first, LOWER INDEX on ties -- also when the K-th score has more copies than places (ties cut by index), on all-equal
+    """K in (48, 1024] takes the radix-select path (smaller and larger K: arg-max rounds): the ranking must be the reference order
+    bit for bit on both -- larger score first, LOWER INDEX on ties -- also when the K-th score has more copies than places (ties cut by index), on all-equal
     maps and for +0 / -0 (equal as floats)."""
     rs = np.random.RandomState({'random': 1, 'quantised': 2, 'constant': 3, 'signed_zero': 4}[case])
     rows, cols = 67, 120
@@ -130,7 +130,7 @@ def test_topk_select_path_matches_rounds_and_reference_order(case):
     l = torch.from_numpy(loc).view(1, 4, rows, cols).cuda()
     # reference order: value descending, index ascending on ties (what K arg-max rounds with "lower index wins" produce)
     order = np.lexsort((np.arange(n), -sc.astype(np.float64)))
-    for K in (40, 49, 300, 1000, 1024):
+    for K in (1, 2, 10, 16, 17, 40, 49, 300, 1000, 1024, 1500):
         dets, topk, keep = DC._run(s, l, rows * 4, cols * 4, K)
         got = topk.cpu().numpy()
         assert np.array_equal(got, order[:K]), (case, K, np.nonzero(got != order[:K])[0][:5])
