@@ -1546,6 +1546,20 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
 #endif
             DBX_SELECT(DBX_K_BAND, 256, 256, "conv3x3_band_kernel", (launch_conv_band<T, 256, 256, 2, 2, 4>(a, s)));
         }
+        // Single-image maps whose 192-pixel tiles fit ONE round of one workgroup per CU (512 x 512 input: conv3 at 128 x 128, conv4 at
+        // 64 x 64): the tile's 72-144 K stages are each a 64-ns MFMA burst behind a ~0.5-us L2 / MALL round trip, so what counts is
+        // how many stages are in flight -- with the whole LDS of a CU to itself a workgroup runs a 4- or 5-deep ring instead of the
+        // 3 stages that two co-resident 128-pixel workgroups can afford (DBX_CONV_VARIANT=8: off).
+        const int tiles192 = (int)((Q + 191) / 192);
+        if (conv_variant() != 8 && x->n == 1 && y->c % 128 == 0 && d->cout_pad % 128 == 0 && y->c <= 256 && tiles192 * (y->c / 128) <= 256 &&
+            tiles192 * (y->c / 128) >= 128) {
+            a.ntile_n = y->c / 128; a.nblocks = tiles192 * a.ntile_n;
+            DBX_SELECT(DBX_K_BAND, 192, 128, "conv3x3_band_kernel", (launch_conv_band<T, 192, 128, 4, 4, 2>(a, s)));
+        }
+        if (conv_variant() != 8 && x->n == 1 && tiles192 * (y->c / 64) <= 256 && tiles192 * (y->c / 64) >= 128) {
+            a.ntile_n = y->c / 64; a.nblocks = tiles192 * a.ntile_n;
+            DBX_SELECT(DBX_K_BAND, 192, 64, "conv3x3_band_kernel", (launch_conv_band<T, 192, 64, 5, 4, 2>(a, s)));
+        }
         if (y->c % 128 == 0 && d->cout_pad % 128 == 0 && (!few128 || y->c == 128)) {
             a.ntile_n = y->c / 128;
             if (tall) { a.nblocks = tiles512 * a.ntile_n; DBX_SELECT(DBX_K_BAND, 512, 128, "conv3x3_band_kernel", (launch_conv_band<T, 512, 128, 2, 4, 2>(a, s))); }
