@@ -1560,6 +1560,13 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             a.ntile_n = y->c / 64; a.nblocks = tiles192 * a.ntile_n;
             DBX_SELECT(DBX_K_BAND, 192, 64, "conv3x3_band_kernel", (launch_conv_band<T, 192, 64, 5, 4, 2>(a, s)));
         }
+        // ... and a 128-cout layer whose 256-pixel tiles number just over one round (conv2 of a 512 x 512 image: 261 workgroups of one
+        // per CU = two rounds, the second with five workgroups): 288-pixel tiles (232) finish in one
+        const int tiles288 = (int)((Q + 287) / 288);
+        if (conv_variant() != 8 && x->n == 1 && y->c == 128 && d->cout_pad == 128 && tiles256 > 256 && tiles288 <= 256) {
+            a.ntile_n = 1; a.nblocks = tiles288;
+            DBX_SELECT(DBX_K_BAND, 288, 128, "conv3x3_band_kernel", (launch_conv_band<T, 288, 128, 3, 2, 4>(a, s)));
+        }
         if (y->c % 128 == 0 && d->cout_pad % 128 == 0 && (!few128 || y->c == 128)) {
             a.ntile_n = y->c / 128;
             if (tall) { a.nblocks = tiles512 * a.ntile_n; DBX_SELECT(DBX_K_BAND, 512, 128, "conv3x3_band_kernel", (launch_conv_band<T, 512, 128, 2, 4, 2>(a, s))); }

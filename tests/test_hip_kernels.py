@@ -44,6 +44,7 @@ CONV_CASES = [  # n, h, w, cin, cout, k, pad
     (1, 64, 64, 512, 512, 3, 1),      # single-image maps: 192-pixel tiles, one workgroup per CU, 5-deep ring (conv4 of a 512 x 512 image)
     (1, 128, 128, 256, 256, 3, 1),    # ... 192 x 128 tiles, 4-deep ring (conv3)
     (1, 64, 60, 256, 512, 3, 1),
+    (1, 256, 256, 64, 128, 3, 1),     # 261 tiles of 256 pixels -> 232 of 288 (conv2_1 of a 512 x 512 image)
 ]
 
 
@@ -72,10 +73,10 @@ def test_conv_forward_kernel(case, dtn, variant, monkeypatch):
     got = ty[:, 1:1 + ho, 1:1 + wo].permute(0, 3, 1, 2).float()
     tol = (2e-2 if dtn == 'bf16' else 3e-3)          # output rounding to the 16-bit type dominates
     assert torch.allclose(got, ref, rtol=tol, atol=tol), (got - ref).abs().max().item()
-    if variant == 'dma' and n == 1 and (h, w) in ((64, 64), (128, 128)) and not os.environ.get('DBX_CONV_VARIANT'):
+    if variant == 'dma' and n == 1 and (h, w) in ((64, 64), (128, 128), (256, 256)) and not os.environ.get('DBX_CONV_VARIANT'):
         plan = _lib.ConvPlan()
         check(L.dbx_conv_plan(C.byref(d), C.byref(xv), C.byref(yv), C.byref(plan)))
-        assert b'conv3x3_band_kernel' in plan.name and b',192,' in plan.name, plan.name
+        assert b'conv3x3_band_kernel' in plan.name and (b',288,' if h == 256 else b',192,') in plan.name, plan.name
     # the zero frame must be untouched
     assert float(ty[:, 0].abs().sum()) == 0 and float(ty[:, :, 0].abs().sum()) == 0
     assert float(ty[:, -1].abs().sum()) == 0 and float(ty[:, :, -1].abs().sum()) == 0
