@@ -246,7 +246,56 @@ __global__ __launch_bounds__(DET_THREADS) void detect_kernel(const DetArgs a) {
     }
     // ---- top-K indices into a.topk, in the reference's order: larger score first, lower index on ties
     const bool select = a.K >= DET_SELECT_MIN_K && a.K <= DET_THREADS;
-    if (select) {
+    const bool tourney = !select && a.K <= 48 && n <= 16 * DET_THREADS;
+    if (tourney) {
+        // Small K on a map of <= 16384 scores (the 512 x 512 input's 128 x 128 map, K = 10): every lane keeps its 16 scores in registers
+        // as (key << 32 | ~index) composites -- larger composite = larger score, lower index on ties, the select path's order -- each
+        // wave extracts ITS top K by K rounds of a register maximum + a wave reduction (shuffles only, no workgroup barrier), the 16
+        // waves leave their sorted lists in LDS and wave 0 merges the 16 K candidates the same way: ~6 us instead of K block-wide
+        // arg-max rounds with three barriers each (30 us at K = 10).
+        unsigned long long* wcand = (unsigned long long*)bidx;            // [16][48]
+        const int lane = tid & 63, wv = tid >> 6;
+        unsigned long long comp[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = tid + e * DET_THREADS;
+            comp[e] = i < n ? ((unsigned long long)det_key(a.score[i]) << 32) | (unsigned)(~(unsigned)i) : 0ull;
+        }
+        auto wave_max = [&](unsigned long long v) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off); v = o > v ? o : v; }
+            return v;
+        };
+        for (int r = 0; r < a.K; ++r) {
+            unsigned long long best = comp[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) best = comp[e] > best ? comp[e] : best;
+            best = wave_max(best);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) comp[e] = comp[e] == best ? 0ull : comp[e];
+            if (lane == 0) wcand[wv * 48 + r] = best;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const int tot = (DET_THREADS / 64) * a.K;                        // <= 768: 12 per lane
+            unsigned long long c2[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int f = lane + 64 * j;
+                c2[j] = f < tot ? wcand[(f / a.K) * 48 + f % a.K] : 0ull;
+            }
+            for (int r = 0; r < a.K; ++r) {
+                unsigned long long best = c2[0];
+#pragma unroll
+                for (int j = 1; j < 12; ++j) best = c2[j] > best ? c2[j] : best;
+                best = wave_max(best);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) c2[j] = c2[j] == best ? 0ull : c2[j];
+                if (lane == 0) a.topk[r] = (long long)(~(unsigned)(best & 0xffffffffull));
+            }
+        }
+        __syncthreads();
+    } else if (select) {
         // K in (48, 1024] (round 3: K = 1000 at 1080p took 4.7 ms as 1000 arg-max rounds): radix select of the K-th largest key
         // (four 8-bit passes, LDS histogram), compaction of the keys above it plus the lowest-index ties, bitonic sort of <= 1024
         // (key, index) pairs in LDS -- ~0.1 ms, the same ranking bit for bit.
