@@ -104,3 +104,38 @@ def test_whole_image_1080p(golden):
     assert tuple(s.shape) == tuple(g['score_shape'])
     _close(s[0, 0, ::9, ::8], g['score_sub'], TOL['f16'], '1080p score')
     _close(l[0, :, ::9, ::8], g['loc_sub'], TOL['f16'], '1080p loc')
+
+
+@pytest.mark.parametrize('size', [(512, 512), (384, 640), (256, 1024)])
+def test_single_image_tiles_agree_with_the_fp32_path(size):
+    """Single-image maps run their own band tiles (192 x 64 / 192 x 128 / 288 x 128, one workgroup per CU with a deep LDS ring) and
+    the register-tournament top-K: the f16 forward of a 512 x 512-class image against the fp32 path of the same network (no reference
+    fixture at these sizes: the fp32 path is pinned by the 240 x 240 / 100 x 132 / 1080p fixtures), and detect() graph replay ==
+    eager == the plain forward + parse + NMS calls."""
+    from densebox_amd import decode as DC
+    h, w = size
+    x = synth.synth_images(1, h, w, seed=7).cuda()
+    net = _net('DenseBoxLMLOC', 'f32', 11)
+    with torch.no_grad():
+        ref = [o.clone() for o in net(x)]
+    net.compute_dtype = 'f16'
+    with torch.no_grad():
+        outs = [o.clone() for o in net(x)]
+    for i, (o, r) in enumerate(zip(outs, ref)):
+        _close(o, r.cpu().numpy(), TOL['f16'], 'single image %dx%d out %d' % (h, w, i), RMS_TOL['f16'])
+    from densebox_amd import _lib
+    plans = {net.engine().conv_plan(_lib.F16, net.engine().last_plan.B[a].view(), net.engine().last_plan.B[b].view(), 3, 3, 1, ci, co, 3)[1]
+             for a, b, ci, co in (('a41', 'a42', 512, 512), ('a31', 'a32', 256, 256), ('a21', 'a22', 128, 128))}
+    if size == (512, 512):
+        assert plans == {'conv3x3_band_kernel<f16,192,64>', 'conv3x3_band_kernel<f16,192,128>', 'conv3x3_band_kernel<f16,288,128>'}, plans
+    dets, keep = net.detect(x, K=10, nms_thresh=0.4)
+    dets2, keep2 = net.detect(x, K=10, nms_thresh=0.4)                      # replay
+    import os
+    os.environ['DBX_GRAPH'] = '0'
+    try:
+        dets3, keep3 = net.detect(x, K=10, nms_thresh=0.4)                  # eager
+    finally:
+        del os.environ['DBX_GRAPH']
+    assert np.array_equal(dets, dets2) and keep == keep2 and np.array_equal(dets, dets3) and keep == keep3
+    want = DC.parse_DetLMLOC(outs[1], outs[2], outs[3], outs[4], h, w, K=10)
+    assert np.array_equal(dets, want)
