@@ -1198,6 +1198,125 @@ extern "C" int dbx_fold_heads(const float* w2, const float* b2, const float* w1,
     return DBX_OK;
 }
 
+// Refine branch in eval mode (DenseBox.py:464-471): pool4 -> conv6_1 (3x3) -> conv6_2 (5x5) -> bilinear up -> conv6_3 (1x1) has no
+// non-linearity after the pooling, the 1x1 conv commutes with the up-sampling (bilinear weights sum to 1, so constants pass through),
+// and two un-padded cross-correlations compose into one: the branch is ONE un-padded 7x7 conv from `ci` channels to 1, then the
+// up-sampling of that single map.   W[c][u][v] = sum_m sum_{a+i=u, b+j=v} (sum_n w3[n] w2[n][m][a][b]) w1[m][c][i][j],
+// b = b3 + sum_n w3[n] b2[n] + sum_m (sum_{a,b} V[m][a][b]) b1[m].  fp32 in, fp32 out; once per weight version.
+__global__ __launch_bounds__(256) void fold_refine_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
+                                                          int ci, int cm, float* __restrict__ w, float* __restrict__ b) {
+    __shared__ float V[64 * 25];
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < cm * 25; e += 256) {                    // V[m][a][b]
+        const int m = e / 25, ab = e % 25;
+        float acc = 0.f;
+        for (int n = 0; n < cm; ++n) acc = fmaf(w3[n], w2[((size_t)n * cm + m) * 25 + ab], acc);
+        V[e] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < ci * 49; e += 256) {
+        const int c = e / 49, u = (e % 49) / 7, v = e % 7;
+        float acc = 0.f;
+        for (int m = 0; m < cm; ++m)
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    const int a2 = u - i, b2i = v - j;
+                    if (a2 >= 0 && a2 < 5 && b2i >= 0 && b2i < 5) acc = fmaf(V[m * 25 + a2 * 5 + b2i], w1[(((size_t)m * ci + c) * 3 + i) * 3 + j], acc);
+                }
+        w[e] = acc;
+    }
+    float part = 0.f;
+    for (int m = tid; m < cm; m += 256) {
+        float sv = 0.f;
+        for (int ab = 0; ab < 25; ++ab) sv += V[m * 25 + ab];
+        part += sv * b1[m] + w3[m] * b2[m];
+    }
+    red[tid] = part;
+    __syncthreads();
+    if (tid == 0) {
+        float acc = b3[0];
+        for (int t = 0; t < 256; ++t) acc += red[t];
+        b[0] = acc;
+    }
+}
+extern "C" int dbx_fold_refine(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                               int32_t ci, int32_t cm, float* w_out, float* b_out, void* stream) {
+    DBX_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && w_out && b_out && ci >= 1 && cm >= 1 && cm <= 64, "fold_refine: bad arguments (mid channels <= 64)");
+    hipLaunchKernelGGL(fold_refine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3, ci, cm, w_out, b_out);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+// The folded branch in one fp32 kernel: cat(landmarks, score) -> MaxPool2d(2, 2) -> the 7x7 conv of dbx_fold_refine, straight from the
+// heads' fp32 NCHW outputs (no layout conversion, no 16-bit rounding inside the branch).  A workgroup makes 16 x 16 outputs from a
+// 22 x 22 x 5 pooled tile it builds in LDS; 245 FMAs per output in a fixed order.
+__global__ __launch_bounds__(256) void refine_eval_kernel(const float* __restrict__ lm, const float* __restrict__ sc, int h, int w,
+                                                          const float* __restrict__ wf, const float* __restrict__ bf, float* __restrict__ out) {
+    constexpr int T = 16, PT = T + 6, CI = 5;
+    __shared__ float tile[CI][PT][PT + 1];
+    __shared__ float wsm[CI * 49];
+    const int ph = h / 2, pw = w / 2, oh = ph - 6, ow = pw - 6;
+    const int n = blockIdx.z, oy0 = blockIdx.y * T, ox0 = blockIdx.x * T;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < CI * 49; e += 256) wsm[e] = wf[e];
+    for (int e = tid; e < CI * PT * PT; e += 256) {
+        const int c = e / (PT * PT), r = e % (PT * PT), py = oy0 + r / PT, px = ox0 + r % PT;
+        float v = 0.f;
+        if (py < ph && px < pw) {
+            const float* p = (c < 4 ? lm + ((size_t)n * 4 + c) * h * w : sc + (size_t)n * h * w) + (size_t)(2 * py) * w + 2 * px;
+            v = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[w], p[w + 1]));
+        }
+        tile[c][r / PT][r % PT] = v;
+    }
+    __syncthreads();
+    const int ty = tid / T, tx = tid % T, oy = oy0 + ty, ox = ox0 + tx;
+    if (oy < oh && ox < ow) {
+        float acc = bf[0];
+        for (int c = 0; c < CI; ++c)
+#pragma unroll
+            for (int u = 0; u < 7; ++u)
+#pragma unroll
+                for (int v = 0; v < 7; ++v) acc = fmaf(wsm[(c * 7 + u) * 7 + v], tile[c][ty + u][tx + v], acc);
+        out[((size_t)n * oh + oy) * ow + ox] = acc;
+    }
+}
+extern "C" int dbx_refine_eval(const float* landmark_nchw, const float* score_nchw, int32_t n, int32_t h, int32_t w, const float* w_fold,
+                               const float* b_fold, float* out_small, void* stream) {
+    DBX_REQUIRE(landmark_nchw && score_nchw && w_fold && b_fold && out_small && n >= 1 && h / 2 >= 7 && w / 2 >= 7, "refine_eval: bad arguments (H/2, W/2 >= 7)");
+    const int oh = h / 2 - 6, ow = w / 2 - 6;
+    hipLaunchKernelGGL(refine_eval_kernel, dim3((ow + 15) / 16, (oh + 15) / 16, n), dim3(256), 0, (hipStream_t)stream, landmark_nchw, score_nchw, h, w,
+                       w_fold, b_fold, out_small);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
+// bilinear up-sampling (align_corners=True, ATen's arithmetic: bilin_coef) of fp32 NCHW planes -- the folded refine branch's single map
+__global__ void upsample_nchw_f32_kernel(const float* __restrict__ x, int planes, int hi, int wi, float* __restrict__ y, int ho, int wo,
+                                         float sy, float sx) {
+    const int64_t total = (int64_t)planes * ho * wo;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % wo), py = (int)((i / wo) % ho);
+        const int64_t pl = i / ((int64_t)wo * ho);
+        int y0, y1, x0, x1;
+        float ly0, ly1, lx0, lx1;
+        bilin_coef(py, sy, hi, y0, y1, ly0, ly1);
+        bilin_coef(px, sx, wi, x0, x1, lx0, lx1);
+        const float* p = x + pl * hi * wi;
+        y[i] = ly0 * (lx0 * p[y0 * wi + x0] + lx1 * p[y0 * wi + x1]) + ly1 * (lx0 * p[y1 * wi + x0] + lx1 * p[y1 * wi + x1]);
+    }
+}
+extern "C" int dbx_upsample_bilinear_nchw_f32(const float* x, int32_t planes, int32_t hi, int32_t wi, float* y, int32_t ho, int32_t wo,
+                                              void* stream) {
+    DBX_REQUIRE(x && y && planes >= 1 && hi >= 1 && wi >= 1 && ho >= 1 && wo >= 1, "upsample_nchw: bad arguments");
+    const int64_t total = (int64_t)planes * ho * wo;
+    hipLaunchKernelGGL(upsample_nchw_f32_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, planes, hi, wi, y, ho, wo,
+                       ac_scale(hi, ho), ac_scale(wi, wo));
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- uint8 HWC image -> network input
 // torchvision's ToTensor + Normalize of the reference datasets (DenseBox.py:766-772, :3613-3619) fused with the layout
 // change: y[n,py,px,c] = ((u8 / 255) - mean[c]) / std[c] in fp32 (true divisions, like ATen), rounded to the compute

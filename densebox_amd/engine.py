@@ -383,6 +383,24 @@ class Engine:
         self.wcache[('folded', dt)] = (ver, (wp, bf, ktot))
         return wp, bf, ktot
 
+    def _w_refine_folded(self):
+        """Eval mode: conv6_1 (3x3) -> conv6_2 (5x5) -> up-sampling -> conv6_3 (1x1) as one un-padded 7x7 conv 5 -> 1 (dbx_fold_refine):
+        (w [1][5][7][7], b [1]) in fp32, cached on the parameter versions."""
+        names = ['conv6_1_det.weight', 'conv6_1_det.bias', 'conv6_2_det.weight', 'conv6_2_det.bias', 'conv6_3_det.weight', 'conv6_3_det.bias']
+        ps = [self._param(nm) for nm in names]
+        ver = tuple((p._version, p.data_ptr()) for p in ps)
+        ent = self.wcache.get(('refold',))
+        if ent is not None and ent[0] == ver:
+            return ent[1]
+        dev = ps[0].device
+        ci, cm = ps[0].shape[1], ps[0].shape[0]
+        assert ci == 5 and cm <= 64 and tuple(ps[0].shape[2:]) == (3, 3) and tuple(ps[2].shape[2:]) == (5, 5)
+        wf = torch.empty((1, ci, 7, 7), dtype=torch.float32, device=dev)
+        bf = torch.zeros(1, dtype=torch.float32, device=dev)
+        check(self.L.dbx_fold_refine(*[ptr(p.detach().float().contiguous()) for p in ps], ci, cm, ptr(wf), ptr(bf), stream_ptr()))
+        self.wcache[('refold',)] = (ver, (wf, bf))
+        return wf, bf
+
     # ------------------------------------------------------------------ plumbing
     def _frag(self, P, dt, stem, which):
         """Does the library run this backbone layer's forward ('f') / data-gradient ('b') conv with fragment-order weights
@@ -591,7 +609,22 @@ class Engine:
             for stem, k in heads:
                 outs[stem] = big[:, o:o + k].contiguous()
                 o += k
-        if kind != 'DenseBox':
+        if kind != 'DenseBox' and not train:
+            # refine branch in eval mode (DenseBox.py:464-471): nothing after the pooling is non-linear, the 1x1 conv commutes with the
+            # up-sampling -> cat + pool + ONE un-padded 7x7 conv 5 -> 1 in a single fp32 kernel on the heads' fp32 outputs, then the
+            # up-sampling of that one map (was: two layout kernels, pool, three convs, a 64-channel up-sampling: 60 us of a 0.46-ms image)
+            wf7, bf7 = self._w_refine_folded()
+            lmk, det = outs['landmark'], outs['det']
+            if not lmk.is_contiguous():
+                lmk = lmk.contiguous()
+            if not det.is_contiguous():
+                det = det.contiguous()
+            small = torch.empty((n, 1, h4 // 2 - 6, w4 // 2 - 6), dtype=torch.float32, device=dev)
+            check(L.dbx_refine_eval(ptr(lmk), ptr(det), n, h4, w4, ptr(wf7), ptr(bf7), ptr(small), s))
+            o = torch.empty((n, 1, h4, w4), dtype=torch.float32, device=dev)
+            check(L.dbx_upsample_bilinear_nchw_f32(ptr(small), n, h4 // 2 - 6, w4 // 2 - 6, ptr(o), h4, w4, s))
+            outs['refine'] = o
+        elif kind != 'DenseBox':
             # refine branch: cat(landmarks, score) -> pool4 -> 3x3 -> 5x5 -> bilinear -> 1x1   (DenseBox.py:464-471)
             rdt = P.rdt
             saved, self._defer = self._defer, None            # (fp32 refine weights: packed on their own, cached on the parameter versions)

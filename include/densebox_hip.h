@@ -165,6 +165,18 @@ int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const dbx_view* hid
  * (no non-linearity in between, DenseBox.py:158-162): w_out[k][768] = w2 w1, b_out[k] = w2 b1 + b2 (all fp32) */
 int dbx_fold_heads(const float* w2, const float* b2, const float* w1, const float* b1, int32_t k, float* w_out,
                    float* b_out, void* stream);
+/* Eval mode, refine branch (pool4 -> conv6_1 3x3 -> conv6_2 5x5 -> bilinear up -> conv6_3 1x1, DenseBox.py:464-471 / :729-736): nothing
+ * after the pooling is non-linear, so the three convs fold into ONE un-padded 7x7 conv ci -> 1 (w_out [1][ci][7][7], b_out [1]) whose
+ * single map is then up-sampled (dbx_upsample_bilinear_nchw_f32: fp32 NCHW planes, align_corners=True, ATen's arithmetic).  w1
+ * [cm][ci][3][3], b1 [cm], w2 [cm][cm][5][5], b2 [cm], w3 [1][cm][1][1], b3 [1]; cm <= 64. */
+int dbx_fold_refine(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                    int32_t ci, int32_t cm, float* w_out, float* b_out, void* stream);
+/* ... and the folded branch itself in one fp32 kernel: cat(landmarks [n][4][h][w], score [n][1][h][w]) (fp32 NCHW, the heads' outputs) ->
+ * MaxPool2d(2, 2) -> that 7x7 conv -> out_small [n][1][h/2 - 6][w/2 - 6]; dbx_upsample_bilinear_nchw_f32 then gives the refined score. */
+int dbx_refine_eval(const float* landmark_nchw, const float* score_nchw, int32_t n, int32_t h, int32_t w, const float* w_fold,
+                    const float* b_fold, float* out_small, void* stream);
+int dbx_upsample_bilinear_nchw_f32(const float* x, int32_t planes, int32_t hi, int32_t wi, float* y, int32_t ho, int32_t wo,
+                                   void* stream);
 
 /* ------------------------------------------------------------------ weight gradient
  * dw[co][ci][ky][kx] (+)= sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-cpad,x+kx-cpad,ci]   (fp32 OIHW, DenseBox.py:2186)

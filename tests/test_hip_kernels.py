@@ -693,3 +693,39 @@ def test_conv_wgrad_slice_writes_a_column_range(dtn):
     assert torch.equal(wide[:, coff:coff + ci], dw) and torch.equal(db, db2)
     assert float((wide[:, :coff] - 7.0).abs().max()) == 0.0
     assert L.dbx_conv_wgrad_slice(dt, C.byref(dzv), C.byref(xv), 1, 1, 0, co, ci, ptr(wide), ctot, coff + 1, ptr(db2), ptr(sc), 0, stream_ptr()) != 0
+
+
+def test_fold_refine_equals_the_three_convs_and_the_upsampling():
+    """dbx_fold_refine (eval-mode refine branch, DenseBox.py:464-471): conv6_1 (3x3) -> conv6_2 (5x5) -> bilinear up -> conv6_3 (1x1) as ONE
+    un-padded 7x7 conv followed by the up-sampling of its single map (dbx_upsample_bilinear_nchw_f32), against the torch chain in fp64."""
+    L = _lib.lib()
+    g = torch.Generator(device='cpu').manual_seed(77)
+    ci, cm = 5, 64
+    w1 = torch.randn(cm, ci, 3, 3, generator=g) * 0.2; b1 = torch.randn(cm, generator=g) * 0.1
+    w2 = torch.randn(cm, cm, 5, 5, generator=g) * 0.05; b2 = torch.randn(cm, generator=g) * 0.1
+    w3 = torch.randn(1, cm, 1, 1, generator=g) * 0.3; b3 = torch.randn(1, generator=g)
+    x = torch.randn(2, ci, 20, 26, generator=g)
+    d = lambda t: t.double()
+    ref = F.conv2d(F.interpolate(F.conv2d(F.conv2d(d(x), d(w1), d(b1)), d(w2), d(b2)), size=(40, 52), mode='bilinear', align_corners=True), d(w3), d(b3))
+    dev = [t.cuda() for t in (w1, b1, w2, b2, w3, b3)]
+    wf = torch.full((1, ci, 7, 7), float('nan'), device='cuda'); bf = torch.full((1,), float('nan'), device='cuda')
+    check(L.dbx_fold_refine(*[ptr(t) for t in dev], ci, cm, ptr(wf), ptr(bf), stream_ptr()))
+    small = F.conv2d(x.cuda(), wf, bf)                                          # [2, 1, 14, 20]
+    out = torch.empty((2, 1, 40, 52), device='cuda')
+    check(L.dbx_upsample_bilinear_nchw_f32(ptr(small.contiguous()), 2, 14, 20, ptr(out), 40, 52, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.allclose(out.double().cpu(), ref, rtol=0, atol=2e-4 * float(ref.abs().max())), float((out.double().cpu() - ref).abs().max())
+    want = F.interpolate(small, size=(40, 52), mode='bilinear', align_corners=True)
+    assert torch.allclose(out, want, rtol=0, atol=1e-5 * float(want.abs().max()))
+    # the whole branch from the heads' fp32 NCHW outputs: cat -> pool4 -> folded conv (one kernel) -> up-sampling, odd map sizes included
+    for hh, ww in ((40, 52), (33, 47), (14, 15)):
+        lmk = torch.randn(2, 4, hh, ww, generator=g); sc = torch.randn(2, 1, hh, ww, generator=g)
+        xin = F.max_pool2d(torch.cat((lmk, sc), dim=1), 2, 2)
+        ref2 = F.conv2d(F.interpolate(F.conv2d(F.conv2d(d(xin), d(w1), d(b1)), d(w2), d(b2)), size=(hh, ww), mode='bilinear', align_corners=True), d(w3), d(b3))
+        sm = torch.full((2, 1, hh // 2 - 6, ww // 2 - 6), float('nan'), device='cuda')
+        lmk_d, sc_d = lmk.cuda(), sc.cuda()                                      # (kept alive: the call takes raw pointers)
+        check(L.dbx_refine_eval(ptr(lmk_d), ptr(sc_d), 2, hh, ww, ptr(wf), ptr(bf), ptr(sm), stream_ptr()))
+        out2 = torch.empty((2, 1, hh, ww), device='cuda')
+        check(L.dbx_upsample_bilinear_nchw_f32(ptr(sm), 2, hh // 2 - 6, ww // 2 - 6, ptr(out2), hh, ww, stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.allclose(out2.double().cpu(), ref2, rtol=0, atol=2e-4 * float(ref2.abs().max())), (hh, ww, float((out2.double().cpu() - ref2).abs().max()))
