@@ -73,8 +73,10 @@ SIGNATURES = {
     'dbx_conv_forward_pool_idx': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _I32, _VP, _VP]),
     'dbx_pack_weight': (C.c_int, [_I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _I32, _I32, _VP]),
     'dbx_fold_heads': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP]),
-    'dbx_fold_refine': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP]),
+    'dbx_fold_refine': (C.c_int, [_VP, _VP, _VP, _VP, _VP, _VP, _I32, _I32, _VP, _VP, _VP, _VP]),
     'dbx_refine_eval': (C.c_int, [_VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP]),
+    'dbx_refine_backward_scratch_bytes': (C.c_int64, [_I32, _I32, _I32]),
+    'dbx_refine_backward': (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'dbx_upsample_bilinear_nchw_f32': (C.c_int, [_VP, _I32, _I32, _I32, _VP, _I32, _I32, _VP]),
     'dbx_pack_multi': (C.c_int, [_I32, _VP, _I32, _I64, _VP]),
     'dbx_head2_dgrad': (C.c_int, [_I32, _PV, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I32, _PV, _VP, _I32, _I32, C.c_uint32, _VP]),

@@ -1203,48 +1203,66 @@ extern "C" int dbx_fold_heads(const float* w2, const float* b2, const float* w1,
 // and two un-padded cross-correlations compose into one: the branch is ONE un-padded 7x7 conv from `ci` channels to 1, then the
 // up-sampling of that single map.   W[c][u][v] = sum_m sum_{a+i=u, b+j=v} (sum_n w3[n] w2[n][m][a][b]) w1[m][c][i][j],
 // b = b3 + sum_n w3[n] b2[n] + sum_m (sum_{a,b} V[m][a][b]) b1[m].  fp32 in, fp32 out; once per weight version.
-__global__ __launch_bounds__(256) void fold_refine_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                                                          const float* __restrict__ b2, const float* __restrict__ w3, const float* __restrict__ b3,
-                                                          int ci, int cm, float* __restrict__ w, float* __restrict__ b) {
-    __shared__ float V[64 * 25];
-    __shared__ float red[256];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < cm * 25; e += 256) {                    // V[m][a][b]
+// V[m][a][b] = sum_n w3[n] w2[n][m][a][b]: 32 outputs per workgroup, eight lanes per output (eight mid channels each), summed by a fixed
+// shuffle tree -- a single workgroup walking the 410 KB of conv6_2 weights took 150 us, and training re-folds after every optimizer step
+__global__ __launch_bounds__(256) void fold_refine_v_kernel(const float* __restrict__ w2, const float* __restrict__ w3, int cm, float* __restrict__ V) {
+    const int e = blockIdx.x * 32 + (threadIdx.x >> 3), part = threadIdx.x & 7;
+    float acc = 0.f;
+    if (e < cm * 25) {
         const int m = e / 25, ab = e % 25;
-        float acc = 0.f;
-        for (int n = 0; n < cm; ++n) acc = fmaf(w3[n], w2[((size_t)n * cm + m) * 25 + ab], acc);
-        V[e] = acc;
+        for (int n = part; n < cm; n += 8) acc = fmaf(w3[n], w2[((size_t)n * cm + m) * 25 + ab], acc);
     }
+    acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+    if (part == 0 && e < cm * 25) V[e] = acc;
+}
+// one workgroup per input channel c: W[c][u][v] from V and w1 (both staged in LDS), 49 outputs x 5 chunks of mid channels, fixed order
+__global__ __launch_bounds__(256) void fold_refine_w_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ b2,
+                                                            const float* __restrict__ w3, const float* __restrict__ b3, const float* __restrict__ Vg,
+                                                            int ci, int cm, float* __restrict__ w, float* __restrict__ b) {
+    __shared__ float V[64 * 25];
+    __shared__ float w1s[64 * 9];
+    __shared__ float red[5][49];
+    __shared__ float bred[256];
+    const int tid = threadIdx.x, c = blockIdx.x;
+    for (int e = tid; e < cm * 25; e += 256) V[e] = Vg[e];
+    for (int e = tid; e < cm * 9; e += 256) w1s[e] = w1[((size_t)(e / 9) * ci + c) * 9 + e % 9];
     __syncthreads();
-    for (int e = tid; e < ci * 49; e += 256) {
-        const int c = e / 49, u = (e % 49) / 7, v = e % 7;
+    if (tid < 245) {
+        const int uv = tid % 49, ch = tid / 49, u = uv / 7, v = uv % 7;
+        const int per = (cm + 4) / 5, m0 = ch * per, m1 = m0 + per < cm ? m0 + per : cm;
         float acc = 0.f;
-        for (int m = 0; m < cm; ++m)
+        for (int m = m0; m < m1; ++m)
             for (int i = 0; i < 3; ++i)
                 for (int j = 0; j < 3; ++j) {
                     const int a2 = u - i, b2i = v - j;
-                    if (a2 >= 0 && a2 < 5 && b2i >= 0 && b2i < 5) acc = fmaf(V[m * 25 + a2 * 5 + b2i], w1[(((size_t)m * ci + c) * 3 + i) * 3 + j], acc);
+                    if (a2 >= 0 && a2 < 5 && b2i >= 0 && b2i < 5) acc = fmaf(V[m * 25 + a2 * 5 + b2i], w1s[m * 9 + i * 3 + j], acc);
                 }
-        w[e] = acc;
+        red[ch][uv] = acc;
     }
-    float part = 0.f;
-    for (int m = tid; m < cm; m += 256) {
-        float sv = 0.f;
-        for (int ab = 0; ab < 25; ++ab) sv += V[m * 25 + ab];
-        part += sv * b1[m] + w3[m] * b2[m];
-    }
-    red[tid] = part;
     __syncthreads();
-    if (tid == 0) {
-        float acc = b3[0];
-        for (int t = 0; t < 256; ++t) acc += red[t];
-        b[0] = acc;
+    if (tid < 49) w[c * 49 + tid] = (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]) + red[4][tid];
+    if (c == 0) {
+        float part = 0.f;
+        for (int m = tid; m < cm; m += 256) {
+            float sv = 0.f;
+            for (int ab = 0; ab < 25; ++ab) sv += V[m * 25 + ab];
+            part += sv * b1[m] + w3[m] * b2[m];
+        }
+        bred[tid] = part;
+        __syncthreads();
+        if (tid == 0) {
+            float acc = b3[0];
+            for (int t = 0; t < 256; ++t) acc += bred[t];
+            b[0] = acc;
+        }
     }
 }
 extern "C" int dbx_fold_refine(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                               int32_t ci, int32_t cm, float* w_out, float* b_out, void* stream) {
-    DBX_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && w_out && b_out && ci >= 1 && cm >= 1 && cm <= 64, "fold_refine: bad arguments (mid channels <= 64)");
-    hipLaunchKernelGGL(fold_refine_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, w1, b1, w2, b2, w3, b3, ci, cm, w_out, b_out);
+                               int32_t ci, int32_t cm, float* w_out, float* b_out, float* v_out, void* stream) {
+    DBX_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && w_out && b_out && v_out && ci >= 1 && cm >= 1 && cm <= 64, "fold_refine: bad arguments (mid channels <= 64)");
+    hipLaunchKernelGGL(fold_refine_v_kernel, dim3((cm * 25 + 31) / 32), dim3(256), 0, (hipStream_t)stream, w2, w3, cm, v_out);
+    DBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fold_refine_w_kernel, dim3(ci), dim3(256), 0, (hipStream_t)stream, w1, b1, b2, w3, b3, v_out, ci, cm, w_out, b_out);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }

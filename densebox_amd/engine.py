@@ -397,9 +397,10 @@ class Engine:
         assert ci == 5 and cm <= 64 and tuple(ps[0].shape[2:]) == (3, 3) and tuple(ps[2].shape[2:]) == (5, 5)
         wf = torch.empty((1, ci, 7, 7), dtype=torch.float32, device=dev)
         bf = torch.zeros(1, dtype=torch.float32, device=dev)
-        check(self.L.dbx_fold_refine(*[ptr(p.detach().float().contiguous()) for p in ps], ci, cm, ptr(wf), ptr(bf), stream_ptr()))
-        self.wcache[('refold',)] = (ver, (wf, bf))
-        return wf, bf
+        vf = torch.empty((cm, 5, 5), dtype=torch.float32, device=dev)
+        check(self.L.dbx_fold_refine(*[ptr(p.detach().float().contiguous()) for p in ps], ci, cm, ptr(wf), ptr(bf), ptr(vf), stream_ptr()))
+        self.wcache[('refold',)] = (ver, (wf, bf, vf))
+        return wf, bf, vf
 
     # ------------------------------------------------------------------ plumbing
     def _frag(self, P, dt, stem, which):
@@ -609,11 +610,14 @@ class Engine:
             for stem, k in heads:
                 outs[stem] = big[:, o:o + k].contiguous()
                 o += k
-        if kind != 'DenseBox' and not train:
-            # refine branch in eval mode (DenseBox.py:464-471): nothing after the pooling is non-linear, the 1x1 conv commutes with the
-            # up-sampling -> cat + pool + ONE un-padded 7x7 conv 5 -> 1 in a single fp32 kernel on the heads' fp32 outputs, then the
-            # up-sampling of that one map (was: two layout kernels, pool, three convs, a 64-channel up-sampling: 60 us of a 0.46-ms image)
-            wf7, bf7 = self._w_refine_folded()
+        lin_rf = os.environ.get('DBX_REFINE_LINEAR', '1') != '0'     # training: the branch by its linear structure (0: the three convs; A/B, tests)
+        P.refine_fwd = None
+        if kind != 'DenseBox' and (not train or lin_rf):
+            # refine branch (DenseBox.py:464-471): nothing after the pooling is non-linear, the 1x1 conv commutes with the up-sampling
+            # -> cat + pool + ONE un-padded 7x7 conv 5 -> 1 in a single fp32 kernel on the heads' fp32 outputs, then the up-sampling of
+            # that one map (was: two layout kernels, pool, three convs, a 64-channel up-sampling: 60 us of a 0.46-ms image).  Training
+            # too: its backward needs none of the 64-channel intermediates either (csrc/refine_ops.hip)
+            wf7, bf7, vf7 = self._w_refine_folded()
             lmk, det = outs['landmark'], outs['det']
             if not lmk.is_contiguous():
                 lmk = lmk.contiguous()
@@ -624,6 +628,8 @@ class Engine:
             o = torch.empty((n, 1, h4, w4), dtype=torch.float32, device=dev)
             check(L.dbx_upsample_bilinear_nchw_f32(ptr(small), n, h4 // 2 - 6, w4 // 2 - 6, ptr(o), h4, w4, s))
             outs['refine'] = o
+            if train:
+                P.refine_fwd = (lmk, det, wf7, vf7)  # the backward pass re-derives everything else from these (dbx_refine_backward)
         elif kind != 'DenseBox':
             # refine branch: cat(landmarks, score) -> pool4 -> 3x3 -> 5x5 -> bilinear -> 1x1   (DenseBox.py:464-471)
             rdt = P.rdt
@@ -803,7 +809,31 @@ class Engine:
                        dm_ld=512 * nh)
 
         # ---- refine branch (DenseBox.py:464-471) backwards
-        if kind != 'DenseBox':
+        override = {}
+        if kind != 'DenseBox' and P.refine_fwd is not None:
+            # by its linear structure: g = up^T(d refine), the folded conv's weight gradient (245 numbers), then every parameter
+            # gradient as a small contraction and the heads' incoming gradients + the branch's contribution (csrc/refine_ops.hip)
+            lmk, det, wf7, vf7 = P.refine_fwd
+            pn = ['conv6_1_det.weight', 'conv6_1_det.bias', 'conv6_2_det.weight', 'conv6_2_det.bias', 'conv6_3_det.weight', 'conv6_3_det.bias']
+            ps = [self._param(nm).detach() for nm in pn]
+            gs = [new_grad(nm) for nm in pn]
+
+            def f32c(t):
+                return None if t is None else t.to(torch.float32).contiguous()
+            g_lm, g_det = f32c(grad_outs.get('landmark')), f32c(grad_outs.get('det'))
+            o_lm = torch.empty((n, 4, h4, w4), dtype=torch.float32, device=dev)
+            o_det = torch.empty((n, 1, h4, w4), dtype=torch.float32, device=dev)
+            need = L.dbx_refine_backward_scratch_bytes(n, h4, w4)
+            if getattr(self, '_rf_scratch', None) is None or self._rf_scratch.numel() < need:
+                self._rf_scratch = torch.empty(int(need), dtype=torch.uint8, device=dev)
+            d_rf = gout('refine', 1)
+            check(L.dbx_refine_backward(ptr(d_rf), ptr(lmk), ptr(det), n, h4, w4, *[ptr(p) for p in ps], ps[0].shape[0], ptr(wf7), ptr(vf7),
+                                        ptr(g_lm), ptr(g_det), ptr(o_lm), ptr(o_det), *[ptr(g_) for g_ in gs], ptr(self._rf_scratch), s))
+            if sink is not None:
+                sink.ready(pn)
+            override = {'landmark': o_lm, 'det': o_det}
+            P.refine_fwd = None
+        elif kind != 'DenseBox':
             d_rfo = B['d_rfo'].view()
             check(L.dbx_nchw_to_framed(dt, ptr(gout('refine', 1)), 1, C.byref(d_rfo), s))
             conv_bwd('conv6_3_det', d_rfo, B['rf_u'].view(), 1, 1, 0, 1, 64)
@@ -820,8 +850,9 @@ class Engine:
         slot = {}
         for i, (stem, k) in enumerate(heads):
             slot[stem] = B['d_out'].view(P.crf * i, P.crf)
-            check(L.dbx_nchw_to_framed(dt, ptr(gout(stem, k)), k, C.byref(slot[stem]), s))
-        if kind != 'DenseBox':
+            src = override.get(stem)
+            check(L.dbx_nchw_to_framed(dt, ptr(src if src is not None else gout(stem, k)), k, C.byref(slot[stem]), s))
+        if kind != 'DenseBox' and not override:
             check(L.dbx_framed_add_ch(dt, C.byref(B['d_rf_in'].view()), 0, 4, C.byref(slot['landmark']), 0, s))
             check(L.dbx_framed_add_ch(dt, C.byref(B['d_rf_in'].view()), 4, 1, C.byref(slot['det']), 0, s))
 

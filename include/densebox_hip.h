@@ -168,15 +168,30 @@ int dbx_fold_heads(const float* w2, const float* b2, const float* w1, const floa
 /* Eval mode, refine branch (pool4 -> conv6_1 3x3 -> conv6_2 5x5 -> bilinear up -> conv6_3 1x1, DenseBox.py:464-471 / :729-736): nothing
  * after the pooling is non-linear, so the three convs fold into ONE un-padded 7x7 conv ci -> 1 (w_out [1][ci][7][7], b_out [1]) whose
  * single map is then up-sampled (dbx_upsample_bilinear_nchw_f32: fp32 NCHW planes, align_corners=True, ATen's arithmetic).  w1
- * [cm][ci][3][3], b1 [cm], w2 [cm][cm][5][5], b2 [cm], w3 [1][cm][1][1], b3 [1]; cm <= 64. */
+ * [cm][ci][3][3], b1 [cm], w2 [cm][cm][5][5], b2 [cm], w3 [1][cm][1][1], b3 [1]; cm <= 64.  v_out [cm][5][5] = sum_n w3[n] w2[n][m] (the
+ * 64 -> 1 fold of conv6_3 into conv6_2, which dbx_refine_backward needs as well). */
 int dbx_fold_refine(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                    int32_t ci, int32_t cm, float* w_out, float* b_out, void* stream);
+                    int32_t ci, int32_t cm, float* w_out, float* b_out, float* v_out, void* stream);
 /* ... and the folded branch itself in one fp32 kernel: cat(landmarks [n][4][h][w], score [n][1][h][w]) (fp32 NCHW, the heads' outputs) ->
  * MaxPool2d(2, 2) -> that 7x7 conv -> out_small [n][1][h/2 - 6][w/2 - 6]; dbx_upsample_bilinear_nchw_f32 then gives the refined score. */
 int dbx_refine_eval(const float* landmark_nchw, const float* score_nchw, int32_t n, int32_t h, int32_t w, const float* w_fold,
                     const float* b_fold, float* out_small, void* stream);
 int dbx_upsample_bilinear_nchw_f32(const float* x, int32_t planes, int32_t hi, int32_t wi, float* y, int32_t ho, int32_t wo,
                                    void* stream);
+/* Training: the backward pass of the same branch by the same linear structure (csrc/refine_ops.hip has the algebra).  With g = the
+ * transposed up-sampling of d_refine and G1 = the folded conv's weight gradient (245 numbers + sum g), every parameter gradient of
+ * conv6_1 / conv6_2 / conv6_3 is a small contraction of G1 with the weights, and the gradient of cat(landmarks, score) is the
+ * transposed folded conv of g routed through the pooling arg-max.  d_refine [n][1][h][w]; landmark [n][4][h][w] / score [n][1][h][w] =
+ * the heads' fp32 NCHW outputs of the forward pass; w_fold / v_fold from dbx_fold_refine; g_landmark / g_score = the incoming gradients of
+ * those two heads (null = zero), out_landmark / out_score = incoming + the branch's contribution; dw* / db* in the parameters' own
+ * layouts (fp32, overwritten); scratch of dbx_refine_backward_scratch_bytes(n, h, w).  All sums in a fixed order (bitwise repeatable).
+ * Reference: loss.backward() through DenseBox.py:464-471 (:2186 / :2731). */
+int64_t dbx_refine_backward_scratch_bytes(int32_t n, int32_t h, int32_t w);
+int dbx_refine_backward(const float* d_refine, const float* landmark, const float* score, int32_t n, int32_t h, int32_t w,
+                        const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                        int32_t cm, const float* w_fold, const float* v_fold, const float* g_landmark, const float* g_score, float* out_landmark,
+                        float* out_score, float* dw1, float* db1, float* dw2, float* db2, float* dw3, float* db3, void* scratch,
+                        void* stream);
 
 /* ------------------------------------------------------------------ weight gradient
  * dw[co][ci][ky][kx] (+)= sum_{n,y,x} dz[n,y,x,co] * x[n,y+ky-cpad,x+kx-cpad,ci]   (fp32 OIHW, DenseBox.py:2186)

@@ -278,3 +278,29 @@ def test_pool_backward_from_argmax_nibbles_equals_activation_reading_backward(go
     assert la == lb and set(ga) == set(gb)
     for k in ga:
         assert torch.equal(ga[k], gb[k]), k
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'f16'])
+def test_refine_branch_by_linearity_equals_the_three_convs(golden, dtype, monkeypatch):
+    """Training step with the refine branch computed by its linear structure (default: one folded 7x7 conv forward, dbx_refine_backward)
+    against DBX_REFINE_LINEAR=0 (conv6_1 / conv6_2 / up-sampling / conv6_3 and their autograd-order backward on the MFMA kernels): same
+    loss and gradients up to fp32 summation order in f32; in f16 the new path has no 16-bit rounding inside the branch, so the
+    conv6_x gradients agree to the rounding of the old path."""
+    g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', dtype)
+
+    def grads(flag):
+        monkeypatch.setenv('DBX_REFINE_LINEAR', flag)
+        net.engine().plans = {}
+        for p in net.parameters():
+            p.grad = None
+        _, loss = _step(g, kind, net, n, x, 0)
+        loss.backward()
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    la, ga = grads('1')
+    lb, gb = grads('0')
+    tol = 2e-5 if dtype == 'f32' else 2e-2
+    assert abs(la - lb) <= (1e-6 if dtype == 'f32' else 2e-3) * abs(lb), (la, lb)
+    assert set(ga) == set(gb)
+    for k in ga:
+        rel = float((ga[k].double() - gb[k].double()).norm() / (gb[k].double().norm() + 1e-30))
+        assert rel <= tol, (k, rel)

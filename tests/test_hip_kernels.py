@@ -709,7 +709,10 @@ def test_fold_refine_equals_the_three_convs_and_the_upsampling():
     ref = F.conv2d(F.interpolate(F.conv2d(F.conv2d(d(x), d(w1), d(b1)), d(w2), d(b2)), size=(40, 52), mode='bilinear', align_corners=True), d(w3), d(b3))
     dev = [t.cuda() for t in (w1, b1, w2, b2, w3, b3)]
     wf = torch.full((1, ci, 7, 7), float('nan'), device='cuda'); bf = torch.full((1,), float('nan'), device='cuda')
-    check(L.dbx_fold_refine(*[ptr(t) for t in dev], ci, cm, ptr(wf), ptr(bf), stream_ptr()))
+    vf = torch.full((cm, 5, 5), float('nan'), device='cuda')
+    check(L.dbx_fold_refine(*[ptr(t) for t in dev], ci, cm, ptr(wf), ptr(bf), ptr(vf), stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.allclose(vf.double().cpu(), torch.einsum('n,nmab->mab', d(w3)[0, :, 0, 0], d(w2)), rtol=0, atol=1e-5)
     small = F.conv2d(x.cuda(), wf, bf)                                          # [2, 1, 14, 20]
     out = torch.empty((2, 1, 40, 52), device='cuda')
     check(L.dbx_upsample_bilinear_nchw_f32(ptr(small.contiguous()), 2, 14, 20, ptr(out), 40, 52, stream_ptr()))
@@ -729,3 +732,49 @@ def test_fold_refine_equals_the_three_convs_and_the_upsampling():
         check(L.dbx_upsample_bilinear_nchw_f32(ptr(sm), 2, hh // 2 - 6, ww // 2 - 6, ptr(out2), hh, ww, stream_ptr()))
         torch.cuda.synchronize()
         assert torch.allclose(out2.double().cpu(), ref2, rtol=0, atol=2e-4 * float(ref2.abs().max())), (hh, ww, float((out2.double().cpu() - ref2).abs().max()))
+
+
+@pytest.mark.parametrize('shape', [(3, 60, 60), (2, 40, 47), (1, 15, 14)])
+def test_refine_backward_equals_autograd_through_the_three_convs(shape):
+    """dbx_refine_backward (training: the refine branch's backward by its linear structure, csrc/refine_ops.hip) against torch autograd in
+    fp64 through cat -> MaxPool2d -> conv6_1 -> conv6_2 -> Upsample(align_corners) -> conv6_3: every parameter gradient and the gradients
+    of the landmark / score head outputs (incoming gradients added), odd map sizes included; two runs are bitwise equal."""
+    n, h, w = shape
+    L = _lib.lib()
+    g = torch.Generator(device='cpu').manual_seed(n * 1000 + h)
+    ci, cm = 5, 64
+    P = [torch.randn(cm, ci, 3, 3, generator=g) * 0.2, torch.randn(cm, generator=g) * 0.1, torch.randn(cm, cm, 5, 5, generator=g) * 0.05,
+         torch.randn(cm, generator=g) * 0.1, torch.randn(1, cm, 1, 1, generator=g) * 0.3, torch.randn(1, generator=g)]
+    lmk = torch.randn(n, 4, h, w, generator=g); sc = torch.randn(n, 1, h, w, generator=g)
+    d_ref = torch.randn(n, 1, h, w, generator=g); g_lm = torch.randn(n, 4, h, w, generator=g); g_sc = torch.randn(n, 1, h, w, generator=g)
+    Pd = [p.double().requires_grad_(True) for p in P]
+    lmd, scd = lmk.double().requires_grad_(True), sc.double().requires_grad_(True)
+    x5 = F.max_pool2d(torch.cat((lmd, scd), dim=1), 2, 2)
+    out = F.conv2d(F.interpolate(F.conv2d(F.conv2d(x5, Pd[0], Pd[1]), Pd[2], Pd[3]), size=(h, w), mode='bilinear', align_corners=True), Pd[4], Pd[5])
+    ((out * d_ref.double()).sum() + (lmd * g_lm.double()).sum() + (scd * g_sc.double()).sum()).backward()
+    dev = [p.cuda() for p in P]
+    wf = torch.empty((1, ci, 7, 7), device='cuda'); bf = torch.empty((1,), device='cuda'); vf = torch.empty((cm, 5, 5), device='cuda')
+    check(L.dbx_fold_refine(*[ptr(t) for t in dev], ci, cm, ptr(wf), ptr(bf), ptr(vf), stream_ptr()))
+    ins = [t.cuda() for t in (d_ref, lmk, sc, g_lm, g_sc)]
+    scratch = torch.empty(L.dbx_refine_backward_scratch_bytes(n, h, w), dtype=torch.uint8, device='cuda')
+
+    def run():
+        outs = [torch.full((n, 4, h, w), float('nan'), device='cuda'), torch.full((n, 1, h, w), float('nan'), device='cuda')]
+        grads = [torch.full(p.shape, float('nan'), device='cuda') for p in P]
+        check(L.dbx_refine_backward(ptr(ins[0]), ptr(ins[1]), ptr(ins[2]), n, h, w, *[ptr(t) for t in dev], cm, ptr(wf), ptr(vf), ptr(ins[3]), ptr(ins[4]),
+                                    ptr(outs[0]), ptr(outs[1]), *[ptr(t) for t in grads], ptr(scratch), stream_ptr()))
+        torch.cuda.synchronize()
+        return outs, grads
+    (o_lm, o_sc), grads = run()
+    (o_lm2, o_sc2), grads2 = run()
+    assert torch.equal(o_lm, o_lm2) and torch.equal(o_sc, o_sc2) and all(torch.equal(a, b) for a, b in zip(grads, grads2))
+    for name, got, want in [('d landmark', o_lm, lmd.grad), ('d score', o_sc, scd.grad)] + [('dP%d' % i, grads[i], Pd[i].grad) for i in range(6)]:
+        err = float((got.double().cpu() - want).abs().max()); scale = float(want.abs().max())
+        assert err <= 1e-4 * scale, (name, err, scale)
+    # no incoming gradients: null pointers mean zero
+    o3 = [torch.empty((n, 4, h, w), device='cuda'), torch.empty((n, 1, h, w), device='cuda')]
+    g3 = [torch.empty(p.shape, device='cuda') for p in P]
+    check(L.dbx_refine_backward(ptr(ins[0]), ptr(ins[1]), ptr(ins[2]), n, h, w, *[ptr(t) for t in dev], cm, ptr(wf), ptr(vf), None, None,
+                                ptr(o3[0]), ptr(o3[1]), *[ptr(t) for t in g3], ptr(scratch), stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.allclose(o3[0].double().cpu(), lmd.grad - g_lm.double(), rtol=0, atol=1e-4 * float(lmd.grad.abs().max()))
