@@ -306,8 +306,10 @@ class Engine:
         self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
         self._w_heads2(dt)
         self._bias(['conv5_2_' + s_ for s_, _ in heads], 64)
-        if kind != 'DenseBox':
-            if P.rdt == dt:       # (eval mode packs the fp32 refine weights on their own: the table is one dtype)
+        # the refine branch runs from its fp32 parameters (folded 7x7 conv, dbx_refine_backward) unless DBX_REFINE_LINEAR=0 in training
+        rf_convs = kind != 'DenseBox' and train and os.environ.get('DBX_REFINE_LINEAR', '1') == '0'
+        if rf_convs:
+            if P.rdt == dt:       # (the table is one dtype)
                 self._w_fwd(dt, 'conv6_1_det', P.crf, 64)
                 self._w_fwd(dt, 'conv6_2_det', 64, 64)
                 self._w_fwd(dt, 'conv6_3_det', 64, 64)
@@ -320,7 +322,7 @@ class Engine:
                 self._w_heads1_bwd_part(dt, 'c', frag=self._frag_heads(P, dt, 'bc'))
             else:
                 self._w_heads1_bwd(dt, frag=self._frag_heads(P, dt, 'b'))
-            if kind != 'DenseBox':
+            if rf_convs:
                 self._w_bwd(dt, 'conv6_3_det', 64, P.crf)
                 self._w_bwd(dt, 'conv6_2_det', 64, 64)
                 self._w_bwd(dt, 'conv6_1_det', 64, 64)
