@@ -93,6 +93,7 @@ SIGNATURES = {
     'dbx_nchw_to_framed': (C.c_int, [_I32, _VP, _I32, _PV, _VP]),
     'dbx_u8hwc_to_framed': (C.c_int, [_I32, _VP, _PV, C.POINTER(C.c_float), C.POINTER(C.c_float), _VP]),
     'dbx_nchw_to_framed_ch': (C.c_int, [_I32, _VP, _I32, _PV, _I32, _VP]),
+    'dbx_nchw_to_framed_slots': (C.c_int, [_I32, _VP, _VP, _I32, _I32, _PV, _VP]),
     'dbx_framed_to_nchw_f32': (C.c_int, [_I32, _PV, _VP, _VP]),
     'dbx_framed_add_ch': (C.c_int, [_I32, _PV, _I32, _I32, _PV, _I32, _VP]),
     'dbx_maxpool2x2': (C.c_int, [_I32, _PV, _PV, _VP]),

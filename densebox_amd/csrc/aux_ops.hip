@@ -81,6 +81,51 @@ extern "C" int dbx_nchw_to_framed(int32_t dtype, const float* x_nchw, int32_t c_
     DBX_DISPATCH_DTYPE(dtype, nchw_to_framed_t, x_nchw, c_src, y, (hipStream_t)stream);
 }
 
+// The heads' gradients in one launch: up to four fp32 NCHW tensors (k[i] planes each) into consecutive `slot`-channel ranges of ONE
+// framed view (dL/d(head outputs): one slot per head, channels k[i] .. slot-1 of a slot zero) -- four launches of ~9 us each otherwise.
+struct SlotSrc { const float* x[4]; int k[4]; };
+template <typename T>
+__global__ void nchw_to_framed_slots_kernel(SlotSrc src, int nslots, int slot, FrameGeo y) {
+    constexpr int V = Vec<T>::N;
+    const int gps = slot / V, cg = nslots * gps;                       // channel groups per slot, in all
+    const int64_t total = (int64_t)y.n * y.h * y.w * cg;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(i % y.w);
+        const int g = (int)((i / y.w) % cg);
+        const int py = (int)((i / ((int64_t)y.w * cg)) % y.h);
+        const int n = (int)(i / ((int64_t)y.w * cg * y.h));
+        const int si = g / gps, c0 = (g % gps) * V;
+        const float* x = si == 0 ? src.x[0] : si == 1 ? src.x[1] : si == 2 ? src.x[2] : src.x[3];
+        const int k = si == 0 ? src.k[0] : si == 1 ? src.k[1] : si == 2 ? src.k[2] : src.k[3];
+        float v[V];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const int c = c0 + j;
+            v[j] = (x && c < k) ? x[(((int64_t)n * k + c) * y.h + py) * y.w + px] : 0.f;
+        }
+        store_vec<T>((T*)y.base + geo_pix(y, n, py, px) + si * slot + c0, v);
+    }
+}
+template <typename T> static int nchw_to_framed_slots_t(const float* const* xs, const int32_t* ks, int nslots, int slot, const dbx_view* y, hipStream_t s) {
+    VIEW_VEC_CHECK(T, y, "nchw_to_framed_slots");
+    DBX_REQUIRE(nslots >= 1 && nslots <= 4 && slot % Vec<T>::N == 0 && y->c == nslots * slot, "nchw_to_framed_slots: 1..4 slots of a multiple of the vector width, view of nslots * slot channels");
+    SlotSrc src;
+    for (int i = 0; i < 4; ++i) {
+        src.x[i] = i < nslots ? xs[i] : nullptr; src.k[i] = i < nslots ? ks[i] : 0;
+        if (i < nslots) DBX_REQUIRE(ks[i] >= 0 && ks[i] <= slot, "nchw_to_framed_slots: k must fit its slot");
+    }
+    FrameGeo g = make_geo<T>(y);
+    const int64_t total = (int64_t)y->n * y->h * y->w * (y->c / Vec<T>::N);
+    hipLaunchKernelGGL(nchw_to_framed_slots_kernel<T>, dim3(grid_for(total)), dim3(256), 0, s, src, nslots, slot, g);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_nchw_to_framed_slots(int32_t dtype, const float* const* x_nchw, const int32_t* k, int32_t nslots, int32_t slot, const dbx_view* y,
+                                        void* stream) {
+    if (!x_nchw || !k || !y) { dbx_set_error("nchw_to_framed_slots: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(dtype, nchw_to_framed_slots_t, x_nchw, k, nslots, slot, y, (hipStream_t)stream);
+}
+
 template <typename T>
 __global__ void framed_to_nchw_kernel(FrameGeo x, float* __restrict__ y) {
     const int64_t total = (int64_t)x.n * x.c * x.h * x.w;

@@ -850,10 +850,17 @@ class Engine:
 
         # ---- head outputs: dL/dout into the per-head slots (+ the refine input gradient)
         slot = {}
+        srcs = []
         for i, (stem, k) in enumerate(heads):
             slot[stem] = B['d_out'].view(P.crf * i, P.crf)
             src = override.get(stem)
-            check(L.dbx_nchw_to_framed(dt, ptr(src if src is not None else gout(stem, k)), k, C.byref(slot[stem]), s))
+            srcs.append(src if src is not None else gout(stem, k))
+        if override or kind == 'DenseBox':         # every head's gradient is final: all slots in one launch
+            check(L.dbx_nchw_to_framed_slots(dt, (C.c_void_p * nh)(*[t.data_ptr() for t in srcs]), (C.c_int32 * nh)(*[k for _, k in heads]), nh, P.crf,
+                                             C.byref(B['d_out'].view()), s))
+        else:
+            for (stem, k), t in zip(heads, srcs):
+                check(L.dbx_nchw_to_framed(dt, ptr(t), k, C.byref(slot[stem]), s))
         if kind != 'DenseBox' and not override:
             check(L.dbx_framed_add_ch(dt, C.byref(B['d_rf_in'].view()), 0, 4, C.byref(slot['landmark']), 0, s))
             check(L.dbx_framed_add_ch(dt, C.byref(B['d_rf_in'].view()), 4, 1, C.byref(slot['det']), 0, s))

@@ -242,6 +242,10 @@ int dbx_u8hwc_to_framed(int32_t dtype, const uint8_t* x_nhwc, const dbx_view* y,
  * (builds cat(landmarks, score), DenseBox.py:464 / :729) */
 int dbx_nchw_to_framed_ch(int32_t dtype, const float* x_nchw, int32_t c_src, const dbx_view* y, int32_t c_dst_off,
                           void* stream);
+/* nslots (<= 4) fp32 NCHW tensors x_nchw[i] (k[i] planes; a null pointer = zeros) into consecutive `slot`-channel ranges of ONE framed
+ * view y (y->c == nslots * slot): channels k[i] .. slot-1 of a range are zeroed.  dL/d(head outputs) of all heads in one launch. */
+int dbx_nchw_to_framed_slots(int32_t dtype, const float* const* x_nchw, const int32_t* k, int32_t nslots, int32_t slot,
+                             const dbx_view* y, void* stream);
 int dbx_framed_to_nchw_f32(int32_t dtype, const dbx_view* x, float* y_nchw, void* stream);
 /* dst[..., c_dst_off+j] += src[..., c_src_off+j], j < n_ch (gradient of the channel concat at DenseBox.py:464) */
 int dbx_framed_add_ch(int32_t dtype, const dbx_view* src, int32_t c_src_off, int32_t n_ch, const dbx_view* dst,

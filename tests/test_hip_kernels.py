@@ -778,3 +778,27 @@ def test_refine_backward_equals_autograd_through_the_three_convs(shape):
                                 ptr(o3[0]), ptr(o3[1]), *[ptr(t) for t in g3], ptr(scratch), stream_ptr()))
     torch.cuda.synchronize()
     assert torch.allclose(o3[0].double().cpu(), lmd.grad - g_lm.double(), rtol=0, atol=1e-4 * float(lmd.grad.abs().max()))
+
+
+@pytest.mark.parametrize('dtn', ['f32', 'bf16', 'f16'])
+def test_nchw_to_framed_slots_equals_one_call_per_slot(dtn):
+    """dbx_nchw_to_framed_slots (all heads' dL/dout in one launch) == dbx_nchw_to_framed into each slot view, bit for bit; a null source is zeros."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    n, h, w = 3, 11, 14
+    slot = 8 if dtn != 'f32' else 32
+    ks = [1, 4, 4, 8]
+    g = torch.Generator(device='cpu').manual_seed(5)
+    xs = [torch.randn(n, k, h, w, generator=g).cuda() for k in ks]
+    fa, ta, va = framed(torch.full((n, 4 * slot, h, w), 7.0), 0, tdt)
+    fb, tb, vb = framed(torch.full((n, 4 * slot, h, w), 7.0), 0, tdt)
+    for i, (x, k) in enumerate(zip(xs, ks)):
+        sv = View(va.ptr, n, h, w, 0, 4 * slot, slot * i, slot)
+        check(L.dbx_nchw_to_framed(dt, ptr(x), k, C.byref(sv), stream_ptr()))
+    check(L.dbx_nchw_to_framed_slots(dt, (C.c_void_p * 4)(*[x.data_ptr() for x in xs]), (C.c_int32 * 4)(*ks), 4, slot, C.byref(vb), stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(fa, fb) and float(tb.float().abs().sum()) > 0
+    check(L.dbx_nchw_to_framed_slots(dt, (C.c_void_p * 4)(xs[0].data_ptr(), None, xs[2].data_ptr(), None), (C.c_int32 * 4)(*ks), 4, slot, C.byref(vb), stream_ptr()))
+    torch.cuda.synchronize()
+    assert float(tb[..., slot:2 * slot].float().abs().sum()) == 0 and float(tb[..., 3 * slot:].float().abs().sum()) == 0
+    assert torch.equal(tb[..., :slot], ta[..., :slot]) and torch.equal(tb[..., 2 * slot:3 * slot], ta[..., 2 * slot:3 * slot])
