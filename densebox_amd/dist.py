@@ -197,7 +197,11 @@ class DataParallel:
             outs = net(x)
             loss = net.loss(outs, bbox, vertices, labels, rand_neg_indices, lm_rand_neg_indices,
                             batch_global=n_global, positive_num_global=positive_num_global, **loss_kw)
-            loss.backward()
+            direct = getattr(loss, '_dbx_direct', None)
+            if direct is not None and all(t.requires_grad for t in direct[0]):
+                torch.autograd.backward(direct[0], direct[1])      # == loss.backward() (gradient 1.0), without the scaling kernels
+            else:
+                loss.backward()
         finally:
             self.reducer.in_step = False
         self.reducer.finish()

@@ -95,6 +95,9 @@ def densebox_loss(kind, outputs, bbox, vertices=None, labels=None, rand_neg_indi
     check(_lib.lib().dbx_loss_forward_backward(C.byref(d), C.byref(io), ptr(scratch), stream_ptr()))
     live = [(t, gg) for t, gg in zip((score, loc, lm, rf, lmloc), g) if t is not None]
     out = _LossFn.apply(loss[0], len(live), *[t for t, _ in live], *[gg for _, gg in live])
+    # A caller that owns the whole step (DataParallel.step) may feed dL/d(out) straight to autograd: loss.backward() is
+    # torch.autograd.backward(outputs, their gradients x 1.0) -- the five d * g multiplications, the ones() and the clone go away
+    out._dbx_direct = ([t for t, _ in live], [gg for _, gg in live])
     if return_debug:
         dbg['half'] = half
         dbg['grads'] = {k: gg for k, gg in zip(('score', 'loc', 'lm', 'rf', 'lmloc'), g) if gg is not None}
