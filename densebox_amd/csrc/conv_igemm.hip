@@ -44,6 +44,7 @@ struct ConvArgs {
     char* y2; const char* gate2;
     int y2_hp, y2_wp, y2_ld, y2_pad, g2_hp, g2_wp, g2_ld, g2_pad;
     int split_c, epi2, cout_valid2;
+    int rowskip;                    // band kernels: tiles over the frame WITHOUT its top / bottom halo rows (q' = (n H + y) Wp + fx)
     unsigned char* pool_idx;        // fused pooling (EPI2_POOL): arg-max nibbles of the pooled map (dbx_maxpool2x2_idx layout), or null
 };
 
@@ -567,8 +568,13 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
         if (pid < AP) {
             const int row = 16 * pid + lr;
             const int chunk = lc ^ dma_swz<BKB>(row);
-            // band ky=0 starts one frame row up and one pixel left of the tile (x frame == output frame: x.pad == cpad == 1)
-            src[i] = a.x + ((q0 + row) - a.x_wp - 1) * (long long)pix_bytes + chunk * 16;
+            // band ky=0 starts one frame row up and one pixel left of the tile (x frame == output frame: x.pad == cpad == 1).
+            // rowskip: the tile runs over q' = (n H + y) Wp + fx (no halo rows: 6 % fewer MFMAs at 30x30, 3 % at 60x60); the frame
+            // position of q' is q' + (2 img + 1) Wp -- a band row past an image seam simply starts 2 Wp further on, and the taps of
+            // valid output pixels never cross a seam (only the dropped halo-column pixels' do)
+            long long fq = q0 + row;
+            if (a.rowskip) { const long long img = fq / ((long long)(a.x_hp - 2) * a.x_wp); fq += (2 * img + 1) * a.x_wp; }
+            src[i] = a.x + (fq - a.x_wp - 1) * (long long)pix_bytes + chunk * 16;
         } else {
             const int pb = pid - AP;
             const int kx = pb / (BN / 16), row = 16 * (pb % (BN / 16)) + lr;
@@ -662,7 +668,8 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
     // are divided out once and then advanced 16 pixels per fragment row; bias is fetched once per column fragment.
     const int cb = n0 + wn * WTN + (lane >> 4) * 4;
     const int epi = a.epi;
-    const int fpix = a.x_hp * a.x_wp, nimg = a.M / a.HoWo;
+    const int fy_lo = a.rowskip ? 1 : 0, fy_hi = a.rowskip ? a.x_hp - 1 : a.x_hp;       // frame rows a tile pixel can sit on: [fy_lo, fy_hi)
+    const int fpix = (fy_hi - fy_lo) * a.x_wp, nimg = a.M / a.HoWo;
     f32x4 bias[NI];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
@@ -673,6 +680,7 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
         n = (int)(q / fpix);
         const int rem = (int)(q - (long long)n * fpix);
         fy = rem / a.x_wp; fx = rem - fy * a.x_wp;
+        fy += fy_lo;
     }
     static_assert(NI % 2 == 0, "fragment pairs");
     const int g4 = lane >> 4;
@@ -718,12 +726,13 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
         }
         if (a.x_wp >= 16) {                                  // one row wrap at most per 16-pixel advance
             fx += 16;
-            if (fx >= a.x_wp) { fx -= a.x_wp; if (++fy == a.x_hp) { fy = 0; ++n; } }
+            if (fx >= a.x_wp) { fx -= a.x_wp; if (++fy == fy_hi) { fy = fy_lo; ++n; } }
         } else {
             const long long q = q0 + wm * WTM + (mi + 1) * 16 + (lane & 15);
             n = (int)(q / fpix);
             const int rem = (int)(q - (long long)n * fpix);
             fy = rem / a.x_wp; fx = rem - fy * a.x_wp;
+            fy += fy_lo;
         }
     }
 }
@@ -1449,6 +1458,7 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.y2 = nullptr; a.gate2 = nullptr; a.split_c = 0; a.epi2 = 0; a.cout_valid2 = 0;
     a.y2_hp = a.y2_wp = a.y2_ld = a.y2_pad = a.g2_hp = a.g2_wp = a.g2_ld = a.g2_pad = 0;
     a.pool_idx = (unsigned char*)pool_idx;
+    a.rowskip = 0;
     if (y2 && (epi2 & EPI2_POOL)) {
         // pooled second destination: the 64 -> 64 halo-tile kernel only (dbx_conv_pool_fusable)
         DBX_REQUIRE(c64_pool_ok<T>(d, x, y), "conv pool: needs a 16-bit 3x3/pad 1 64 -> 64 layer on congruent frames with even H, W and a bias/ReLU epilogue");
@@ -1531,7 +1541,11 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     // 3x3 / pad 1 on congruent frames (x.pad == 1), 16-bit, plain NHWC epilogue: the band kernel over the linearised frame
     if (!smallc && sizeof(T) == 2 && (conv_variant() == 0 || conv_variant() >= 4) && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 &&
         !(d->epilogue & (DBX_EPI_F32_NCHW | DBX_EPI_DROPMASK | DBX_EPI_DROPHASH)) && (d->cin_pad * ES) % 64 == 0 && y->c % 64 == 0) {
-        const long long Q = (long long)x->n * a.x_hp * a.x_wp;
+        // tiles over the frame without its top / bottom halo rows (DBX_BAND_ROWSKIP=0: over the whole frame, as rounds 1-2 did)
+        static int rowskip = -1;
+        if (rowskip < 0) { const char* e = getenv("DBX_BAND_ROWSKIP"); rowskip = e ? atoi(e) : 1; }
+        a.rowskip = rowskip && (long long)x->h * a.x_wp >= 16 ? 1 : 0;
+        const long long Q = (long long)x->n * (a.rowskip ? x->h : a.x_hp) * a.x_wp;
         const int tiles256 = (int)((Q + 255) / 256), tiles512 = (int)((Q + 511) / 512);
         const bool tall = conv_variant() != 4 && tiles512 >= 1024;      // enough work for >= 4 tall tiles per CU
         // small problems (single-image inference: 64x64 or 128x128 maps): a wide tile would leave most CUs without a workgroup,
