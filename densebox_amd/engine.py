@@ -381,9 +381,12 @@ class Engine:
             o += k
         saved, self._defer = self._defer, None          # pack immediately (not part of the multi-tensor table)
         wp = self._pack(dt, 0, wf, 64, 768, 1, 1)
+        # the two halves of the concat separately (eval by linearity: the conv4_4 part runs on conv4_4's own grid)
+        wpa = self._pack(dt, 0, wf[:, :512].contiguous(), 64, 512, 1, 1)
+        wpc = self._pack(dt, 0, wf[:, 512:].contiguous(), 64, 256, 1, 1)
         self._defer = saved
-        self.wcache[('folded', dt)] = (ver, (wp, bf, ktot))
-        return wp, bf, ktot
+        self.wcache[('folded', dt)] = (ver, (wp, bf, ktot, wpa, wpc))
+        return wp, bf, ktot, wpa, wpc
 
     def _w_refine_folded(self):
         """Eval mode: conv6_1 (3x3) -> conv6_2 (5x5) -> up-sampling -> conv6_3 (1x1) as one un-padded 7x7 conv 5 -> 1 (dbx_fold_refine):
@@ -567,7 +570,12 @@ class Engine:
         conv3('conv4_2_1', 'a41', 'a42', 512, 512)
         conv3('conv4_3_1', 'a42', 'a43', 512, 512)
         conv3('conv4_4_1', 'a43', 'a44', 512, 512)
-        check(L.dbx_upsample_bilinear(dt, C.byref(B['a44'].view()), C.byref(B['fusion'].view(0, 512)), s))
+        # eval: the folded heads are linear in fusion = [up(a44); c34] and have only sum(k) outputs, so W [up(a44); c34] = up(W_a a44) + W_c c34:
+        # the conv4_4 part runs on conv4_4's own grid and its 17 fp32 planes are up-sampled instead of 512 activation channels
+        # (DBX_EVAL_LINEAR=0: up-sample the activations and run one 768-channel GEMM, as training must)
+        lin_eval = not train and os.environ.get('DBX_EVAL_LINEAR', '1') != '0'
+        if not lin_eval:
+            check(L.dbx_upsample_bilinear(dt, C.byref(B['a44'].view()), C.byref(B['fusion'].view(0, 512)), s))
 
         heads = _HEADS[kind]
         nh = len(heads)
@@ -575,10 +583,18 @@ class Engine:
         h4, w4 = P.h4, P.w4
         if not train:
             # eval: Dropout is the identity and the heads have no non-linearity -> one folded 768 -> sum(k) GEMM
-            wp, bf, ktot = self._w_heads_folded(dt)
+            wp, bf, ktot, wpa, wpc = self._w_heads_folded(dt)
             big = torch.empty((n, ktot, h4, w4), dtype=torch.float32, device=dev)
             yv = View(C.c_void_p(big.data_ptr()), n, h4, w4, 0, ktot, 0, ktot)
-            self._conv(dt, B['fusion'].view(), yv, wp, bf, 1, 1, 0, 768, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
+            if lin_eval:
+                h8, w8 = B['a44'].h, B['a44'].w
+                ga = torch.empty((n, ktot, h8, w8), dtype=torch.float32, device=dev)
+                gv = View(C.c_void_p(ga.data_ptr()), n, h8, w8, 0, ktot, 0, ktot)
+                self._conv(dt, B['a44'].view(), gv, wpa, None, 1, 1, 0, 512, 64, _lib.EPI_F32_NCHW)
+                check(L.dbx_upsample_bilinear_nchw_f32(ptr(ga), n * ktot, h8, w8, ptr(big), h4, w4, s))
+                self._conv(dt, B['fusion'].view(512, 256), yv, wpc, bf, 1, 1, 0, 256, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW | _lib.EPI_ACCUM)
+            else:
+                self._conv(dt, B['fusion'].view(), yv, wp, bf, 1, 1, 0, 768, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
             o = 0
             for stem, k in heads:
                 outs[stem] = big[:, o:o + k].contiguous()
