@@ -103,6 +103,7 @@ SIGNATURES = {
     'dbx_maxpool2x2_bwd_idx': (C.c_int, [_I32, _VP, _PV, _PV, _I32, _I32, _VP]),
     'dbx_upsample_bilinear': (C.c_int, [_I32, _PV, _PV, _VP]),
     'dbx_upsample_bilinear_bwd': (C.c_int, [_I32, _PV, _PV, _PV, _VP]),
+    'dbx_loss_scratch_bytes': (C.c_int64, [_I32]),
     'dbx_loss_forward_backward': (C.c_int, [C.POINTER(LossDesc), C.POINTER(LossIO), _VP, _VP]),
     'dbx_count_positives': (C.c_int, [_VP, _VP, _I32, _VP, _VP]),
     'dbx_init_score_map': (C.c_int, [_VP, _VP, _I32, _VP, _VP]),

@@ -356,6 +356,10 @@ extern "C" int dbx_maxpool2x2_bwd_idx(int32_t dtype, const void* idx, const dbx_
 // ---------------------------------------------------------------------------------------------- bilinear, align_corners=True
 // ATen: scale = (in-1)/(out-1) in float; src = scale*dst; i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0.
 __device__ __forceinline__ void bilin_coef(int d, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+    // no FMA contraction here: the compiler unrolls a grid-stride loop by two into v_pk_* instructions and folds scale * d - i0 into one
+    // (packed) fma there but not in the scalar remainder iteration -- l1 then differs by an ulp of src and a value depends on where in the
+    // batch its plane sits (HIP's __fmul_rn is a plain product: it does not stop the contraction, the pragma does)
+#pragma clang fp contract(off)
     const float src = scale * (float)d;
     i0 = (int)src;
     if (i0 > in - 1) i0 = in - 1;
@@ -1367,7 +1371,12 @@ __global__ void upsample_nchw_f32_kernel(const float* __restrict__ x, int planes
         bilin_coef(py, sy, hi, y0, y1, ly0, ly1);
         bilin_coef(px, sx, wi, x0, x1, lx0, lx1);
         const float* p = x + pl * hi * wi;
-        y[i] = ly0 * (lx0 * p[y0 * wi + x0] + lx1 * p[y0 * wi + x1]) + ly1 * (lx0 * p[y1 * wi + x0] + lx1 * p[y1 * wi + x1]);
+        {   // (no contraction: see bilin_coef)
+#pragma clang fp contract(off)
+            const float top = lx0 * p[y0 * wi + x0] + lx1 * p[y0 * wi + x1];
+            const float bot = lx0 * p[y1 * wi + x0] + lx1 * p[y1 * wi + x1];
+            y[i] = ly0 * top + ly1 * bot;
+        }
     }
 }
 extern "C" int dbx_upsample_bilinear_nchw_f32(const float* x, int32_t planes, int32_t hi, int32_t wi, float* y, int32_t ho, int32_t wo,

@@ -91,7 +91,9 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
     return t;   // valid on thread 0
 }
 
-struct LossArgs { dbx_loss_desc d; dbx_loss_io io; double* partial; };
+struct LossArgs { dbx_loss_desc d; dbx_loss_io io; double* partial; unsigned char* maskbuf; };
+#define LOSS_APPLY_THREADS 256
+#define LOSS_APPLY_BLOCKS ((NPIX + LOSS_APPLY_THREADS - 1) / LOSS_APPLY_THREADS)      // 15 workgroups per patch in the second kernel
 
 __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(const LossArgs a) {
     __shared__ float negl[NPIX];
@@ -124,14 +126,69 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(const LossArgs a) {
         if (tid == 0) io.pos_count[n] = (int)t;
     }
     // ---- hard negatives: top-K of the negative loss (descending; DenseBox.py:2083), then the random draws
-    for (int k = 0; k < K; ++k) {
-        const int idx = block_argmax(negl, red_v, red_i);
-        if (tid == 0) {
-            negl[idx] = -1.f;
-            mask[idx] = 1;
-            if (io.neg_idx) io.neg_idx[(size_t)n * 2 * K + k] = idx;
+    if (K > 0 && K <= 48) {
+        // register tournament (as detect_kernel's): every lane holds its four losses as (bits << 32 | ~index) composites -- the losses
+        // are >= +0, so their bit patterns order like the numbers; larger composite = larger loss, LOWER index on ties, the order of
+        // the arg-max rounds below -- each wave extracts its top K with register maxima + shuffles, wave 0 merges the 16 lists:
+        // no workgroup barrier per selected pixel (24 -> 5 us at K = 11).  A NaN loss ranks with the zeros.
+        __shared__ unsigned long long wcand[(LOSS_THREADS / 64) * 48];
+        const int lane = tid & 63, wv = tid >> 6;
+        unsigned long long comp[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = tid + e * LOSS_THREADS;
+            const float v = i < NPIX ? negl[i] : 0.f;
+            const unsigned key = v != v ? 0u : __float_as_uint(v);
+            comp[e] = i < NPIX ? ((unsigned long long)key << 32) | (unsigned)(~(unsigned)i) : 0ull;
+        }
+        auto wave_max = [&](unsigned long long v) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { const unsigned long long o = __shfl_xor(v, off); v = o > v ? o : v; }
+            return v;
+        };
+        for (int r = 0; r < K; ++r) {
+            unsigned long long best = comp[0];
+#pragma unroll
+            for (int e = 1; e < 4; ++e) best = comp[e] > best ? comp[e] : best;
+            best = wave_max(best);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) comp[e] = comp[e] == best ? 0ull : comp[e];
+            if (lane == 0) wcand[wv * 48 + r] = best;
         }
         __syncthreads();
+        if (wv == 0) {
+            const int tot = (LOSS_THREADS / 64) * K;                         // <= 768: 12 per lane
+            unsigned long long c2[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) {
+                const int f = lane + 64 * j;
+                c2[j] = f < tot ? wcand[(f / K) * 48 + f % K] : 0ull;
+            }
+            for (int r = 0; r < K; ++r) {
+                unsigned long long best = c2[0];
+#pragma unroll
+                for (int j = 1; j < 12; ++j) best = c2[j] > best ? c2[j] : best;
+                best = wave_max(best);
+#pragma unroll
+                for (int j = 0; j < 12; ++j) c2[j] = c2[j] == best ? 0ull : c2[j];
+                if (lane == 0) {
+                    const int idx = (int)(~(unsigned)(best & 0xffffffffull));
+                    mask[idx] = 1;
+                    if (io.neg_idx) io.neg_idx[(size_t)n * 2 * K + r] = idx;
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+        for (int k = 0; k < K; ++k) {
+            const int idx = block_argmax(negl, red_v, red_i);
+            if (tid == 0) {
+                negl[idx] = -1.f;
+                mask[idx] = 1;
+                if (io.neg_idx) io.neg_idx[(size_t)n * 2 * K + k] = idx;
+            }
+            __syncthreads();
+        }
     }
     for (int k = tid; k < K; k += LOSS_THREADS) {
         const long long r = io.rand_neg[(size_t)n * K + k];
@@ -190,12 +247,41 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(const LossArgs a) {
         }
     }
 
-    // ---- weighted sums and gradients
+    // ---- masks to the scratch buffer: the weighted sums and the gradients are a second, full-grid kernel (the 18 maps of a patch are
+    // 260 KB of loads and stores: 36 of this kernel's 79 us when one workgroup per patch did them)
+    unsigned char* mb = a.maskbuf + (size_t)n * 5 * NPIX;
+    for (int i = tid; i < NPIX; i += LOSS_THREADS) {
+        mb[i] = mask[i];
+        if (kind != 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mb[(1 + j) * NPIX + i] = lmask[j][i];
+        }
+    }
+}
+
+// second kernel: one lane per output pixel, 15 workgroups per patch; the same expressions in the same order per pixel, the patch's sums
+// as 15 partials added in a fixed order by loss_finish_kernel
+__global__ __launch_bounds__(LOSS_APPLY_THREADS) void loss_apply_kernel(const LossArgs a) {
+    __shared__ double red_d[LOSS_APPLY_THREADS / 64];
+    const int n = blockIdx.y, tid = threadIdx.x, i = blockIdx.x * LOSS_APPLY_THREADS + tid;
+    const int kind = a.d.kind;
+    const dbx_loss_io& io = a.io;
+    const float* bb = io.bbox + 4 * n;
+    const int valid = (a.d.use_labels && io.labels) ? (io.labels[n] != 0.f) : 1;
+    const Box box = make_box(bb, valid);
+    const float* score = io.score + (size_t)n * NPIX;
+    const unsigned char* mb = a.maskbuf + (size_t)n * 5 * NPIX;
+    int lmx[4] = {0, 0, 0, 0}, lmy[4] = {0, 0, 0, 0};
+    if (kind != 0) {
+        const float* vt = io.vertices + 8 * n;
+        const int clamp = a.d.use_labels;
+        for (int j = 0; j < 4; ++j) { lmx[j] = lm_coord(vt[2 * j], clamp); lmy[j] = lm_coord(vt[2 * j + 1], clamp); }
+    }
     const float l_loc = a.d.lambda_loc, l_det = (kind == 0) ? 1.f : a.d.lambda_det, l_lm = a.d.lambda_lm;
     double s_cls = 0, s_loc = 0, s_lm = 0, s_lmloc = 0, s_rf = 0;
-    for (int i = tid; i < NPIX; i += LOSS_THREADS) {
+    if (i < NPIX) {
         const int y = i / HWD, x = i - y * HWD;
-        const float m = (float)mask[i];
+        const float m = (float)mb[i];
         const float gt = (valid && in_span(box.py, y) && in_span(box.px, x)) ? 1.f : 0.f;
         if (io.mask_cls) io.mask_cls[(size_t)n * NPIX + i] = m;
         {
@@ -219,7 +305,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(const LossArgs a) {
             if (io.d_rf) io.d_rf[(size_t)n * NPIX + i] = 2.f * m * d;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float ml = (float)lmask[j][i];
+                const float ml = (float)mb[(1 + j) * NPIX + i];
                 const float hg = (valid && i == lmy[j] * HWD + lmx[j]) ? 1.f : 0.f;
                 const size_t o = ((size_t)n * 4 + j) * NPIX + i;
                 const float dl = io.lm[o] - hg;
@@ -241,19 +327,41 @@ __global__ __launch_bounds__(LOSS_THREADS) void loss_kernel(const LossArgs a) {
         }
     }
     // full = l_det*(cls + l_loc*loc) + l_lm*lm + lmloc + rf      (DenseBox.py:2166-2180, :2711-2723, :2917)
-    const double mine = (double)l_det * (s_cls + (double)l_loc * s_loc) + (double)l_lm * s_lm + s_lmloc + s_rf;
-    const double tot = block_sum(mine, red_d);
-    if (tid == 0) a.partial[n] = tot;
-}
-
-__global__ void loss_finish_kernel(const double* partial, int n, float* loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double mine = (double)l_det * (s_cls + (double)l_loc * s_loc) + (double)l_lm * s_lm + s_lmloc + s_rf;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((tid & 63) == 0) red_d[tid >> 6] = mine;
+    __syncthreads();
+    if (tid == 0) {
         double t = 0.0;
-        for (int i = 0; i < n; ++i) t += partial[i];       // fixed order: deterministic
-        loss[0] = (float)t;
+        for (int w = 0; w < LOSS_APPLY_THREADS / 64; ++w) t += red_d[w];
+        a.partial[(size_t)n * LOSS_APPLY_BLOCKS + blockIdx.x] = t;
     }
 }
 
+// n patches x `per` partials: every thread adds the partials of its patches in order, thread 0 then adds the patch sums in patch order
+// (fixed order: deterministic; one thread walking all 960 partials took 49 us of dependent global loads)
+__global__ __launch_bounds__(256) void loss_finish_kernel(const double* partial, int n, int per, float* loss) {
+    __shared__ double psum[256];
+    double run = 0.0;                                         // thread 0 only: running total over groups of 256 patches
+    for (int base = 0; base < n; base += 256) {
+        const int p = base + threadIdx.x;
+        double t = 0.0;
+        if (p < n) for (int i = 0; i < per; ++i) t += partial[(size_t)p * per + i];
+        psum[threadIdx.x] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int cnt = n - base < 256 ? n - base : 256;
+            for (int i = 0; i < cnt; ++i) run += psum[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = (float)run;
+}
+
+extern "C" int64_t dbx_loss_scratch_bytes(int32_t n) {          // per-workgroup partial sums (double) + the five mask planes of every patch
+    return (int64_t)n * LOSS_APPLY_BLOCKS * 8 + (int64_t)n * 5 * NPIX + 64;
+}
 extern "C" int dbx_loss_forward_backward(const dbx_loss_desc* d, const dbx_loss_io* io, void* scratch, void* stream) {
     DBX_REQUIRE(d && io && scratch, "loss: null argument");
     DBX_REQUIRE(d->kind >= 0 && d->kind <= 2 && d->n > 0, "loss: bad kind/n");
@@ -262,9 +370,12 @@ extern "C" int dbx_loss_forward_backward(const dbx_loss_desc* d, const dbx_loss_
     if (d->kind != 0) DBX_REQUIRE(io->vertices && io->lm && io->rf && io->lm_rand_neg, "loss: landmark tensors missing");
     if (d->kind == 2) DBX_REQUIRE(io->lmloc != nullptr, "loss: lm_loc missing");
     LossArgs a; a.d = *d; a.io = *io; a.partial = (double*)scratch;
+    a.maskbuf = (unsigned char*)scratch + (size_t)d->n * LOSS_APPLY_BLOCKS * sizeof(double);
     hipLaunchKernelGGL(loss_kernel, dim3(d->n), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a);
     DBX_LAUNCH_CHECK();
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)scratch, d->n, io->loss);
+    hipLaunchKernelGGL(loss_apply_kernel, dim3(LOSS_APPLY_BLOCKS, d->n), dim3(LOSS_APPLY_THREADS), 0, (hipStream_t)stream, a);
+    DBX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)scratch, d->n, LOSS_APPLY_BLOCKS, io->loss);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }

@@ -29,6 +29,10 @@ constexpr int RCI = 5, RTAPS = 49, RG1 = RCI * RTAPS + 1;              // G1 (24
 
 // ATen's align_corners=True source coordinate (same arithmetic as aux_ops.hip::bilin_coef)
 __device__ __forceinline__ void rf_coef(int d, float scale, int in, int& i0, int& i1, float& l0, float& l1) {
+    // no FMA contraction here: the compiler unrolls a grid-stride loop by two into v_pk_* instructions and folds scale * d - i0 into one
+    // (packed) fma there but not in the scalar remainder iteration -- l1 then differs by an ulp of src and a value depends on where in the
+    // batch its plane sits (HIP's __fmul_rn is a plain product: it does not stop the contraction, the pragma does)
+#pragma clang fp contract(off)
     const float src = scale * (float)d;
     i0 = (int)src;
     if (i0 > in - 1) i0 = in - 1;

@@ -74,7 +74,7 @@ def densebox_loss(kind, outputs, bbox, vertices=None, labels=None, rand_neg_indi
     o = [c32(t) for t in (score, loc, lm, rf, lmloc)]
     g = [None if t is None else torch.empty_like(t) for t in o]
     loss = torch.empty(1, dtype=torch.float32, device=dev)
-    scratch = torch.empty(n, dtype=torch.float64, device=dev)
+    scratch = torch.empty((_lib.lib().dbx_loss_scratch_bytes(n) + 7) // 8, dtype=torch.float64, device=dev)
     dbg = {}
     if return_debug:
         dbg['mask_cls'] = torch.empty((n, 1, 60, 60), dtype=torch.float32, device=dev)

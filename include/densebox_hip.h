@@ -296,7 +296,9 @@ typedef struct dbx_loss_io {
     int32_t* pos_count;      /* [n] positives per sample out or NULL */
 } dbx_loss_io;
 
-/* scratch: d->n doubles (per-patch partial sums, reduced in fixed order) */
+/* scratch: dbx_loss_scratch_bytes(d->n) bytes, 8-byte aligned (per-workgroup partial sums, reduced in a fixed order, and the mask planes
+ * the mining kernel hands to the gradient kernel) */
+int64_t dbx_loss_scratch_bytes(int32_t n);
 int dbx_loss_forward_backward(const dbx_loss_desc* d, const dbx_loss_io* io, void* scratch, void* stream);
 /* positives per sample from the boxes alone (a5) -- lets the host derive half_neg without reading maps back */
 int dbx_count_positives(const float* bbox, const float* labels, int32_t n, int32_t* count_per_sample, void* stream);
