@@ -121,3 +121,34 @@ def test_fused_loss_vs_reference_capture(golden, name):
         if i in direct:       # outputs that do not feed the refine branch: the captured gradient is the direct one
             cap = g['s0_dout_%d' % i]
             assert np.allclose(o.grad.cpu().numpy(), cap, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(cap).max())), i
+
+
+@pytest.mark.parametrize('half', [1, 11, 48, 49, 130])
+def test_mining_paths_match_the_oracle_for_small_and_large_k(golden, half):
+    """The hard-negative top-K runs as a register tournament for K <= 48 and as K block-wide arg-max rounds above: both must give the
+    oracle's index list (descending loss; the reference's torch.topk leaves the order of exactly equal losses unspecified, so the maps are
+    continuous random numbers: no ties above the K-th loss) and masks bit for bit, and its loss -- K is forced through positive_num_global."""
+    g = golden('train_DenseBoxLMLOC')
+    kind = 'DenseBoxLMLOC'
+    n = 3
+    rs = np.random.RandomState(100 + half)
+    shapes = [(n, 1, 60, 60), (n, 1, 60, 60), (n, 4, 60, 60), (n, 4, 60, 60), (n, 8, 60, 60)]
+    outs_np = [rs.randn(*sh).astype(np.float32) for sh in shapes]
+    rand_neg = np.stack([rs.choice(3600, half, replace=False) for _ in range(n)])
+    lm_rand = np.stack([np.stack([rs.choice(3600, 1, replace=False) for _ in range(n)]) for _ in range(4)])
+    P = 2 * half * n                                                                             # neg_counts(P, n) -> half
+    assert LB.neg_counts(P, n)[1] == half
+    outs = [T(o).cuda().requires_grad_(True) for o in outs_np]
+    loss, dbg = densebox_loss(kind, tuple(outs), g['bbox'][:n], g['vert'][:n], g['lab'][:n], rand_neg_indices=rand_neg,
+                              lm_rand_neg_indices=lm_rand, return_debug=True, batch_global=n, positive_num_global=P)
+    leaf = [T(o).requires_grad_(True) for o in outs_np]
+    res = O.loss_step(kind, tuple(leaf), g['bbox'][:n], g['vert'][:n], g['lab'][:n], rand_neg=rand_neg, lm_rand_neg=lm_rand,
+                      batch_global=n, positive_num_global=P)
+    assert dbg['half'] == half == res['half']
+    assert np.array_equal(dbg['neg_idx'].cpu().numpy(), res['neg_idx'])
+    assert np.array_equal(dbg['mask_cls'].cpu().numpy(), res['mask'])
+    assert np.isclose(float(loss.detach()), float(res['loss'].detach()), rtol=2e-6)
+    loss.backward(); res['loss'].backward()
+    for o, l in zip(outs, leaf):
+        ref = l.grad.numpy()
+        assert np.allclose(o.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref).max()))
