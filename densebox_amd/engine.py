@@ -400,9 +400,12 @@ class Engine:
         dev = ps[0].device
         ci, cm = ps[0].shape[1], ps[0].shape[0]
         assert ci == 5 and cm <= 64 and tuple(ps[0].shape[2:]) == (3, 3) and tuple(ps[2].shape[2:]) == (5, 5)
-        wf = torch.empty((1, ci, 7, 7), dtype=torch.float32, device=dev)
-        bf = torch.zeros(1, dtype=torch.float32, device=dev)
-        vf = torch.empty((cm, 5, 5), dtype=torch.float32, device=dev)
+        if ent is not None and ent[1][0].device == dev:          # training re-folds after every optimizer step: same three buffers
+            wf, bf, vf = ent[1]
+        else:
+            wf = torch.empty((1, ci, 7, 7), dtype=torch.float32, device=dev)
+            bf = torch.empty(1, dtype=torch.float32, device=dev)
+            vf = torch.empty((cm, 5, 5), dtype=torch.float32, device=dev)
         check(self.L.dbx_fold_refine(*[ptr(p.detach().float().contiguous()) for p in ps], ci, cm, ptr(wf), ptr(bf), ptr(vf), stream_ptr()))
         self.wcache[('refold',)] = (ver, (wf, bf, vf))
         return wf, bf, vf
