@@ -84,6 +84,8 @@ SIGNATURES = {
     'dbx_head2_wgrad': (C.c_int, [_I32, _PV, _PV, C.POINTER(C.c_int32), _I32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _VP]),
     'dbx_head2_backward': (C.c_int, [_I32, _PV, _PV, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I32, _PV, _VP, _I32, _I32, C.c_uint32,
                                      C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _VP]),
+    'dbx_head2_backward_up': (C.c_int, [_I32, _PV, _PV, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I32, _PV, _VP, _I32, _I32, C.c_uint32,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _PV, _VP]),
     'dbx_perspective_matrix': (C.c_int, [_VP, _VP, _VP]),
     'dbx_warp_perspective_u8': (C.c_int, [_VP, _I32, _I32, _I32, _VP, _VP, _I32, _I32, _VP]),
     'dbx_conv_wgrad_scratch_bytes': (_I64, [_I32, _PV, _PV, _I32, _I32]),

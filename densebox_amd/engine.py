@@ -901,6 +901,8 @@ class Engine:
         h2_names = ['conv5_2_%s.weight' % st for st, _ in heads] + ['conv5_2_%s.bias' % st for st, _ in heads]
         mask_p = C.c_void_p(P.mask_buf.data_ptr()) if (P.drop_active and not P.drop_hash) else None
         hash_on, hash_seed = (1 if P.drop_hash else 0), (P.drop_seed if P.drop_hash else 0)
+        lin = self._lin_bwd(dt)
+        up_done = False
         if side is not None:
             def run_h2():
                 check(L.dbx_head2_wgrad(dt, C.byref(B['d_out'].view()), C.byref(hv), ks, nh,
@@ -911,6 +913,12 @@ class Engine:
             on_side(run_h2)
             check(L.dbx_head2_dgrad(dt, C.byref(B['d_out'].view()), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]), ks, nh,
                                     C.byref(B['d_hid'].view()), mask_p, 512 * nh, hash_on, hash_seed, s))
+        elif lin:   # one pass over the pixels, and the hidden gradient goes to conv4_4's grid (d_g44 = up^T(d_hid)) while it is in registers
+            check(L.dbx_head2_backward_up(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]), ks, nh,
+                                          C.byref(B['d_hid'].view()), mask_p, 512 * nh, hash_on, hash_seed,
+                                          (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
+                                          ptr(self._h2_scratch), C.byref(B['d_g44'].view()), s))
+            up_done = True
         else:       # one pass over the pixels: the d_hid write overlaps the hid read
             check(L.dbx_head2_backward(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]), ks, nh,
                                        C.byref(B['d_hid'].view()), mask_p, 512 * nh, hash_on, hash_seed,
@@ -920,7 +928,7 @@ class Engine:
                 sink.ready(h2_names)
         if prof is not None:
             ev1.record()
-            prof.append({'kernel': 'head2_wgrad_kernel<%s>' % ('f16', 'bf16', 'f32')[dt],
+            prof.append({'kernel': ('head2_backward_up_kernel<%s>' if up_done else 'head2_wgrad_kernel<%s>') % ('f16', 'bf16', 'f32')[dt],
                          'flops': 2.0 * hv.n * hv.h * hv.w * 512 * sum(k for _, k in heads) * (1 if side is not None else 2), 'start': ev0, 'end': ev1})
         w1n = ['conv5_1_%s.weight' % st for st, _ in heads]
         b1n = ['conv5_1_%s.bias' % st for st, _ in heads]
@@ -930,8 +938,7 @@ class Engine:
             dw1 = torch.empty((512 * nh, 768, 1, 1), dtype=torch.float32, device=dev)
             db1 = torch.empty((512 * nh,), dtype=torch.float32, device=dev)
         c34 = B['fusion'].view(512, 256)
-        lin = self._lin_bwd(dt)
-        if lin:
+        if lin and not up_done:
             # the hidden gradient on conv4_4's grid: d_g44 = up^T(d_hid) (one HBM-bound pass over the 2048-channel map)
             check(L.dbx_upsample_bilinear_bwd(dt, C.byref(B['d_hid'].view()), C.byref(B['d_g44'].view()), None, s))
 

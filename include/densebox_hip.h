@@ -160,6 +160,13 @@ int dbx_head2_wgrad(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, c
 int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const float* const* w2, const int32_t* k,
                        int32_t nh, const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash,
                        uint32_t drop_seed, float* const* dw, float* const* db, void* scratch, void* stream);
+/* The same plus d_g44 = up^T(d_hid), the transposed bilinear up-sampling (align_corners, DenseBox.py:446-449) of the hidden gradient
+ * onto conv4_4's grid -- dbx_upsample_bilinear_bwd(d_hid, d_g44, no gate) -- in the same pass: the 2048-channel gradient is not read
+ * back.  d_hid is bitwise dbx_head2_dgrad's and d_g44 bitwise dbx_upsample_bilinear_bwd's; dw/db are summed per image (fixed order).
+ * 16-bit types run fused when d_hid is up to 64 and d_g44 up to 32 pixels wide (up-sampling by ~2); everything else runs the two passes. */
+int dbx_head2_backward_up(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const float* const* w2, const int32_t* k,
+                          int32_t nh, const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash,
+                          uint32_t drop_seed, float* const* dw, float* const* db, void* scratch, const dbx_view* d_g44, void* stream);
 
 /* eval-mode folding of one head, Conv1x1(768->512) -> Dropout(identity) -> Conv1x1(512->k), into a single 768->k map
  * (no non-linearity in between, DenseBox.py:158-162): w_out[k][768] = w2 w1, b_out[k] = w2 b1 + b2 (all fp32) */

@@ -431,6 +431,66 @@ def test_head2_backward_fused_equals_separate_calls(dtn, drop):
     assert all(torch.equal(a, b) for a, b in zip(dw1, dw2)) and all(torch.equal(a, b) for a, b in zip(db1, db2))
 
 
+@pytest.mark.parametrize('dtn', ['bf16', 'f16', 'f32'])
+@pytest.mark.parametrize('drop', ['hash', 'mask', 'none'])
+@pytest.mark.parametrize('geom', [(3, 60, 60, 30, 30), (2, 23, 37, 12, 19), (2, 10, 64, 9, 32), (2, 10, 64, 9, 33), (1, 12, 70, 6, 35)])
+def test_head2_backward_up_equals_backward_then_transposed_upsampling(geom, drop, dtn):
+    """dbx_head2_backward_up == dbx_head2_backward followed by dbx_upsample_bilinear_bwd (no gate): d_hid and d_g44 bit for bit, the
+    weight/bias gradients up to the order of the fp32 sums (per image instead of per pixel range); repeatable bit for bit.  f32 and maps
+    wider than 64 pixels take the two passes inside the entry point."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    n, h, w, hs, ws = geom
+    ks = [1, 4, 4, 8] if n < 3 else [2, 4]
+    nh = len(ks)
+    g = torch.Generator(device='cpu').manual_seed(11 + h)
+    hid = torch.randn(n, 512 * nh, h, w, generator=g).cuda()
+    dout = torch.zeros(n, 8 * nh, h, w)
+    for i, k in enumerate(ks):
+        dout[:, 8 * i:8 * i + k] = torch.randn(n, k, h, w, generator=g)
+    dout = dout.cuda()
+    w2 = [(torch.randn(k, 512, generator=g) * 0.05).cuda().contiguous() for k in ks]
+    fh, th, hv = framed(hid, 0, tdt)
+    fo, to, dv = framed(dout, 0, tdt)
+    mask = (torch.rand(n * h * w, 512 * nh, generator=g) < 0.5).to(torch.uint8).cuda() if drop == 'mask' else None
+    use_hash, seed = (1, 0xC0DE) if drop == 'hash' else (0, 0)
+    sc = torch.empty(L.dbx_head2_wgrad_scratch_bytes(nh, n * h), dtype=torch.uint8, device='cuda')
+    karr = (C.c_int32 * nh)(*ks)
+    wp = (C.c_void_p * nh)(*[t.data_ptr() for t in w2])
+
+    def outs():
+        fd, td, dhv = framed(torch.zeros(n, 512 * nh, h, w), 0, tdt)
+        fg, tg, dgv = framed(torch.zeros(n, 512 * nh, hs, ws), 1, tdt)
+        dws = [torch.full((k, 512), 7.0, device='cuda') for k in ks]
+        dbs = [torch.full((k,), 7.0, device='cuda') for k in ks]
+        return fd, td, dhv, fg, tg, dgv, dws, dbs
+
+    def fused(o):
+        fd, td, dhv, fg, tg, dgv, dws, dbs = o
+        check(L.dbx_head2_backward_up(dt, C.byref(dv), C.byref(hv), wp, karr, nh, C.byref(dhv), ptr(mask), 512 * nh, use_hash, seed,
+                                      (C.c_void_p * nh)(*[t.data_ptr() for t in dws]), (C.c_void_p * nh)(*[t.data_ptr() for t in dbs]),
+                                      ptr(sc), C.byref(dgv), stream_ptr()))
+        torch.cuda.synchronize()
+    o1 = outs()
+    fd1, td1, dhv1, fg1, tg1, dgv1, dw1, db1 = o1
+    check(L.dbx_head2_backward(dt, C.byref(dv), C.byref(hv), wp, karr, nh, C.byref(dhv1), ptr(mask), 512 * nh, use_hash, seed,
+                               (C.c_void_p * nh)(*[t.data_ptr() for t in dw1]), (C.c_void_p * nh)(*[t.data_ptr() for t in db1]),
+                               ptr(sc), stream_ptr()))
+    check(L.dbx_upsample_bilinear_bwd(dt, C.byref(dhv1), C.byref(dgv1), None, stream_ptr()))
+    torch.cuda.synchronize()
+    o2 = outs()
+    fused(o2)
+    fd2, td2, dhv2, fg2, tg2, dgv2, dw2, db2 = o2
+    assert float(td2.float().abs().sum()) > 0 and float(tg2.float().abs().sum()) > 0
+    assert torch.equal(fd1, fd2)
+    assert torch.equal(fg1, fg2), (fg1.float() - fg2.float()).abs().max().item()
+    for a, b in zip(dw1 + db1, dw2 + db2):
+        assert (a - b).abs().max().item() <= 2e-5 * a.abs().max().item() + 1e-5
+    o3 = outs()
+    fused(o3)
+    assert torch.equal(fg2, o3[3]) and all(torch.equal(a, b) for a, b in zip(dw2 + db2, o3[6] + o3[7]))
+
+
 @pytest.mark.parametrize('dtn', ['bf16', 'f16'])
 @pytest.mark.parametrize('shape', [(3, 40, 72), (2, 18, 34), (16, 64, 128)])
 def test_conv_forward_pool_equals_conv_then_maxpool(shape, dtn):
