@@ -1137,69 +1137,74 @@ extern "C" int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const db
 // ---------------------------------------------------------------------------------------------- stage-2 heads backward + up^T
 // dbx_head2_backward_up: dbx_head2_backward AND the transposed bilinear up-sampling of the hidden gradient it writes
 // (d_g44 = up^T(d_hid): dbx_upsample_bilinear_bwd without a gate) in ONE pass over the hidden map.  The separate up^T pass re-read
-// the 944 MB d_hid it had just been written (311 us at batch 64); here a workgroup owns (image, 64-channel slice) and streams the
-// image's rows top to bottom -- 8 lanes x 16 bytes per pixel, 128-byte segments of a pixel's channels -- so the hidden gradient of a
-// row is in registers when the rows of conv4_4's grid that interpolate from it are accumulated: every lane keeps the y-reduced
-// values of the two source rows its pixel column feeds (va, vb), and when the walk leaves a source row the row is reduced over x
-// through LDS and stored.  Coefficients, order of accumulation (y before x, ascending) and rounding points (d_hid rounded to T first)
-// are those of upsample_bwd_walk_kernel; d_hid is bitwise head2_dgrad_kernel's.  The weight-gradient partials are one block per
-// image (summed over the image's lanes in a fixed order), combined by head2_wgrad_reduce_kernel as before.
-template <typename T>
-__global__ __launch_bounds__(512) void head2_backward_up_kernel(FrameGeo dout, FrameGeo hid, FrameGeo dhid, FrameGeo dg, int nh, int slot,
-                                                                Head2Args ha, float* __restrict__ partial, float* __restrict__ bpartial,
-                                                                const unsigned char* __restrict__ mask, int mask_ld, int use_hash,
-                                                                unsigned drop_seed, float sy, float sx) {
+// the 944 MB d_hid that had just been written (311 us at batch 64).  Here a workgroup owns (64-channel slice, half of the image width)
+// and streams rows top to bottom, image after image -- 8 lanes x 16 bytes per pixel, 128-byte segments of a pixel's channels -- so
+// the hidden gradient of a row is in registers when the rows of conv4_4's grid that interpolate from it are accumulated: every lane
+// keeps the y-reduced values of the two source rows its pixel column feeds (va, vb); when the walk leaves a source row the row goes
+// to an LDS ring and NB rows at a time are reduced over x and stored.  The two halves of a row overlap by the few destination
+// columns both sides' source columns interpolate from (their d_hid is computed twice, stored and accumulated by the owner only), so
+// the halves are independent workgroups: 256 threads, two per CU -- one's barriers and x reductions run under the other's streaming
+// (one 512-thread workgroup per CU lost ~25 % to them).  Coefficients, order of accumulation (y before x, ascending) and rounding
+// points (d_hid rounded to T first) are those of upsample_bwd_walk_kernel; d_hid is bitwise head2_dgrad_kernel's.  The
+// weight-gradient partials are one block per workgroup (fixed order), combined by head2_wgrad_reduce_kernel as before.
 #ifndef H2U_D
 #define H2U_D 2
-#endif
-#ifndef H2U_DBG
-#define H2U_DBG 0
 #endif
 #ifndef H2U_NB
 #define H2U_NB 4
 #endif
-    constexpr int V = 8, CS = 64, LPP = CS / V, D = H2U_D;
+#ifndef H2U_WGS
+#define H2U_WGS 512
+#endif
+struct H2UHalf { int px_lo, px_n, own_lo, own_hi, ix_lo, ix_n; };      // pixel columns walked / owned [own_lo, own_hi), source columns reduced
+struct H2UPlan { int halves; H2UHalf h[2]; };
+template <typename T>
+__global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout, FrameGeo hid, FrameGeo dhid, FrameGeo dg, int nh, int slot,
+                                                                   Head2Args ha, float* __restrict__ partial, float* __restrict__ bpartial,
+                                                                   const unsigned char* __restrict__ mask, int mask_ld, int use_hash,
+                                                                   unsigned drop_seed, float sy, float sx, H2UPlan plan) {
+    constexpr int V = 8, CS = 64, LPP = CS / V, D = H2U_D, PW = 32, NB = H2U_NB, NT = 6;
     static_assert(sizeof(T) == 2, "16-bit element types");
-    __shared__ int s_x0[64], s_lo[64], s_hi[64];
+    __shared__ int s_x0[64], s_lo[32], s_hi[32];
     __shared__ float s_l0[64], s_l1[64];
-    // ring of 2 * NB row buffers [W][CS] fp32 (dynamic LDS): NB finished source rows are x-reduced behind ONE barrier -- with a single
-    // workgroup per CU a barrier stalls the CU until its slowest wave's loads have landed, every second row was ~25 % of the kernel
-    constexpr int NB = H2U_NB;
     extern __shared__ __attribute__((aligned(16))) char h2u_smem[];
-    float* const s_v = (float*)h2u_smem;
-    const int nsl = hid.c / CS;
-    const int sl = blockIdx.x % nsl, grp = blockIdx.x / nsl, G = gridDim.x / nsl;     // the workgroup walks images grp, grp + G, ...
+    float* const s_v = (float*)h2u_smem;                                // ring of 2 * NB row buffers [PW][CS] fp32
+    const int nsl = hid.c / CS, H = hid.h, W = hid.w;
+    int b = blockIdx.x;
+    const int sl = b % nsl; b /= nsl;
+    const int half = b % plan.halves, grp = b / plan.halves, G = gridDim.x / (nsl * plan.halves);   // images grp, grp + G, ...
+    const H2UHalf hf = half ? plan.h[1] : plan.h[0];
     const int hd = sl / (512 / CS), cbase = (sl % (512 / CS)) * CS;
-    const int px = threadIdx.x / LPP, ch = threadIdx.x % LPP, c0 = cbase + ch * V;
-    const int H = hid.h, W = hid.w;
-    const bool active = px < W;
+    const int pl = threadIdx.x / LPP, ch = threadIdx.x % LPP, c0 = cbase + ch * V;
+    const int px = hf.px_lo + pl;
+    const bool active = pl < hf.px_n, owner = active && px >= hf.own_lo && px < hf.own_hi;
     if (threadIdx.x < W) {
         int x0, x1; float lx0, lx1;
         bilin_coef((int)threadIdx.x, sx, dg.w, x0, x1, lx0, lx1);
         s_x0[threadIdx.x] = x0; s_l0[threadIdx.x] = x1 == x0 ? lx0 + lx1 : lx0; s_l1[threadIdx.x] = x1 == x0 ? 0.f : lx1;
     }
     __syncthreads();
-    if (threadIdx.x < dg.w) {                    // destination columns that interpolate from source column ix or ix - 1 (x0 is non-decreasing)
-        const int ix = threadIdx.x;
+    if (threadIdx.x < hf.ix_n) {                 // destination columns that interpolate from source column ix or ix - 1 (x0 is non-decreasing)
+        const int ix = hf.ix_lo + threadIdx.x;
         int lo = W, hi = -1;
         for (int ox = 0; ox < W; ++ox) { const int x0 = s_x0[ox]; if (x0 == ix || x0 == ix - 1) { if (ox < lo) lo = ox; hi = ox; } }
-        s_lo[ix] = lo; s_hi[ix] = hi;
+        s_lo[threadIdx.x] = lo; s_hi[threadIdx.x] = hi;
     }
     __syncthreads();
-    // the x reduction of a finished source row: thread -> (source column tix, channel quad tq), its <= NT destination columns (those with
-    // x0 == tix - 1 or tix: fewer than 2 / sx + 1) and their weights in registers
-    constexpr int NT = 6;
-    const int tix = threadIdx.x / (CS / 4), tq = threadIdx.x % (CS / 4);
-    const bool xtask = tix < dg.w;
+    // the x reduction of a finished source row: thread -> (source column, channel quad), its <= NT destination columns (fewer than
+    // 2 / sx + 1) as row-buffer positions and their weights in registers
+    const int tl = threadIdx.x / (CS / 4), tq = threadIdx.x % (CS / 4), tix = hf.ix_lo + tl;
+    const bool xtask = tl < hf.ix_n;
     int tlo = 0, tcnt = 0;
     float tcf[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) tcf[t] = 0.f;
     if (xtask) {
-        tlo = s_lo[tix]; tcnt = s_hi[tix] - tlo + 1;
+        const int lo = s_lo[tl];
+        tcnt = s_hi[tl] - lo + 1; tlo = lo - hf.px_lo;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int ox = tlo + t < W ? tlo + t : W - 1;
+            const int ox = lo + t < W ? lo + t : W - 1;
             tcf[t] = s_x0[ox] == tix ? s_l0[ox] : s_l1[ox];
         }
     }
@@ -1215,67 +1220,68 @@ __global__ __launch_bounds__(512) void head2_backward_up_kernel(FrameGeo dout, F
 #pragma unroll
     for (int i = 0; i < V; ++i) va[i] = vb[i] = 0.f;
     { int k; head2_load_w<V>(ha, hd, c0, active, w, k); }
-    u32x4 graw[D], hraw[D];
-    int fn = grp, foy = 0;                                              // the next row to fetch (the pipeline runs across images)
-    // addresses = uniform row base (scalar registers) + a per-lane 32-bit element offset fixed for the whole walk: geo_pix per pixel is a
-    // 64-bit vector multiply (quarter-rate instructions), three of them per row were ~a quarter of the loop's VALU time
+    // addresses = uniform row base (scalar registers) + a per-lane 32-bit element offset fixed for the whole walk (geo_pix per pixel is a
+    // 64-bit vector multiply: quarter-rate instructions)
     auto row_of = [](const FrameGeo& g, int img, int y) { return ((size_t)(img * g.hp + y + g.pad) * g.wp) * (size_t)g.ld; };
-    const int pxl = active ? px : W - 1;                                // idle lanes load the row's last pixel (no predicated loads, below)
+    const int pxl = active ? px : hf.px_lo + hf.px_n - 1;               // idle lanes load the last pixel column (no predicated loads, below)
     const unsigned lo_dout = (unsigned)((pxl + dout.pad) * dout.ld + hd * slot), lo_hid = (unsigned)((pxl + hid.pad) * hid.ld + hd * 512 + c0);
     const unsigned lo_dhid = (unsigned)((px + dhid.pad) * dhid.ld + hd * 512 + c0);
     const unsigned lo_dg = (unsigned)((tix + dg.pad) * dg.ld + hd * 512 + cbase + tq * 4);
-    const unsigned lo_mask = (unsigned)(px * mask_ld + hd * 512 + c0);
+    const unsigned lo_mask = (unsigned)(pxl * mask_ld + hd * 512 + c0);
+    const int R = ((hid.n - grp + G - 1) / G) * H;                      // rows this workgroup walks
+    int fn = grp, foy = 0, fr = 0;                                      // the next row to fetch (the pipeline runs across images; it stops at the last row)
+    u32x4 graw[D], hraw[D];
     auto fetch = [&](int d) {
         graw[d] = *(const u32x4*)((const T*)dout.base + row_of(dout, fn, foy) + lo_dout);
         hraw[d] = *(const u32x4*)((const T*)hid.base + row_of(hid, fn, foy) + lo_hid);
+        if (fr + 1 < R) { ++fr; if (++foy == H) { foy = 0; fn += G; } }
     };
-    const int R = ((hid.n - grp + G - 1) / G) * H;                      // rows this workgroup walks
-    int fr = 0;                                                         // index of the row (fn, foy); it stops at the last one
-    auto fetch_adv = [&]() { if (fr + 1 < R) { ++fr; if (++foy == H) { foy = 0; fn += G; } } };
-    int n = grp;
-    const int rowsz = W * CS;
-    int wr = 0, pend = 0, pend_iy = 0;                                  // ring write index, rows waiting for their x reduction (consecutive)
+    int n = grp, wr = 0, pend = 0, pend_iy = 0;                         // image; ring write index, rows waiting for their x reduction (consecutive)
     auto flush = [&]() {                                                // called by every thread of the workgroup
         __syncthreads();
-        if (xtask && !(H2U_DBG & 8)) {
+        if (xtask) {
             for (int p = 0; p < pend; ++p) {
-                const float* buf = s_v + ((wr - pend + p) % (2 * NB)) * rowsz;
+                const float* buf = s_v + ((wr - pend + p) % (2 * NB)) * (PW * CS);
                 f32x4 c = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {                          // the taps' loads are independent: one LDS latency per row
-                    const int ox = tlo + t < W ? tlo + t : W - 1;
-                    const f32x4 a = *(const f32x4*)&buf[ox * CS + tq * 4];
+                    const int o = tlo + t < PW ? tlo + t : PW - 1;
+                    const f32x4 a = *(const f32x4*)&buf[o * CS + tq * 4];
                     if (t < tcnt) { c.x = fmaf(tcf[t], a.x, c.x); c.y = fmaf(tcf[t], a.y, c.y); c.z = fmaf(tcf[t], a.z, c.z); c.w = fmaf(tcf[t], a.w, c.w); }
                 }
                 u32x2 raw;
                 T* e = (T*)&raw;
                 e[0] = from_f32<T>(c.x); e[1] = from_f32<T>(c.y); e[2] = from_f32<T>(c.z); e[3] = from_f32<T>(c.w);
-                if (!(H2U_DBG & 4) || raw.x == 0x12345678u) *(u32x2*)((T*)dg.base + row_of(dg, n, pend_iy + p) + lo_dg) = raw;
+                *(u32x2*)((T*)dg.base + row_of(dg, n, pend_iy + p) + lo_dg) = raw;
             }
         }
         pend = 0;
     };
     auto finalize = [&](int iy, const float (&v)[V]) {          // source row iy of image n is complete
-        float* buf = s_v + (wr % (2 * NB)) * rowsz;
+        float* buf = s_v + (wr % (2 * NB)) * (PW * CS);
         if (active) {
-            *(f32x4*)&buf[px * CS + ch * V] = (f32x4){v[0], v[1], v[2], v[3]};
-            *(f32x4*)&buf[px * CS + ch * V + 4] = (f32x4){v[4], v[5], v[6], v[7]};
+            *(f32x4*)&buf[pl * CS + ch * V] = (f32x4){v[0], v[1], v[2], v[3]};
+            *(f32x4*)&buf[pl * CS + ch * V + 4] = (f32x4){v[4], v[5], v[6], v[7]};
         }
         if (pend == 0) pend_iy = iy;
         ++wr; ++pend;
         if (pend == NB) flush();
     };
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-    { fetch(d); fetch_adv(); }
+    for (int d = 0; d < D; ++d) fetch(d);
+    // The row body has no branches: idle and halo lanes compute on the clamped loads and only the d_hid store is predicated (their sums are
+    // dropped after the walk) -- a per-lane branch around the body costs a copy of every live accumulator at its end -- and all eight d_out
+    // channels are multiplied out although the heads have k = 1, 4, 4, 8 (the rest is zero padding): skipping them behind scalar
+    // branches measured 5-10 % SLOWER (620-660 us against 593), specialised copies of the walk per k 50 % slower (four loop bodies in
+    // the instruction cache of a CU pair).  ~250 VALU instructions per row and wave, 2/3 of the issue slots (rocprofv3 SQ_INSTS_VALU).
     int cur = 0, oy = 0;
     for (int r0 = 0; r0 < R; r0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int r = r0 + d;
-            // The loads are unconditional (rows past the end re-read the last row, idle lanes the last pixel): a load under a condition
-            // makes its destination a phi, the compiler copies it at the end of the block and WAITS for the load there -- the row just
-            // requested instead of the one needed D rows later (measured: 1.4 us per row, the exposed memory latency)
+            // The loads are unconditional (rows past the end re-read the last row, idle lanes the last pixel column): a load under a
+            // condition makes its destination a phi, the compiler copies it at the end of the block and WAITS for the load there -- the
+            // row just requested instead of the one needed D rows later
             float gj[8], h[V];
             {
                 const T* ge = (const T*)&graw[d];
@@ -1285,33 +1291,30 @@ __global__ __launch_bounds__(512) void head2_backward_up_kernel(FrameGeo dout, F
 #pragma unroll
                 for (int i = 0; i < V; ++i) h[i] = to_f32(he[i]);
             }
-            fetch(d); fetch_adv();
+            fetch(d);
             if (r < R) {                                                // (uniform)
                 int y0, y1; float ly0, ly1;
                 bilin_coef(oy, sy, dg.h, y0, y1, ly0, ly1);
                 while (y0 > cur) {                                      // (uniform) the walk left source row `cur`
-                    if (!(H2U_DBG & 1)) finalize(cur, va);
+                    finalize(cur, va);
 #pragma unroll
                     for (int i = 0; i < V; ++i) { va[i] = vb[i]; vb[i] = 0.f; }
                     ++cur;
                 }
                 const float wa = (y0 == cur ? ly0 : 0.f) + (y1 == cur ? ly1 : 0.f);
                 const float wb = (y0 == cur + 1 ? ly0 : 0.f) + (y1 == cur + 1 ? ly1 : 0.f);
-                if (active) {
+                {
+                    float o[V];                                       // same arithmetic and order as head2_dgrad_kernel (its terms past k are + 0)
+#pragma unroll
+                    for (int i = 0; i < V; ++i) o[i] = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         bs[j] += gj[j];
                         const f32x2 g2 = {gj[j], gj[j]};
 #pragma unroll
                         for (int i = 0; i < V / 2; ++i) acc[j][i] = g2 * (f32x2){h[2 * i], h[2 * i + 1]} + acc[j][i];
-                    }
-                    float o[V];                                       // same arithmetic and order as head2_dgrad_kernel
 #pragma unroll
-                    for (int i = 0; i < V; ++i) {
-                        float a2 = 0.f;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) a2 += gj[j] * w[j][i];
-                        o[i] = a2;
+                        for (int i = 0; i < V; ++i) o[i] = fmaf(gj[j], w[j][i], o[i]);
                     }
                     const long long pc0 = ((long long)n * H + oy) * W;          // (uniform) index of the row's first pixel
                     if (mask) {
@@ -1331,16 +1334,14 @@ __global__ __launch_bounds__(512) void head2_backward_up_kernel(FrameGeo dout, F
                     T* oe = (T*)&raw;
 #pragma unroll
                     for (int i = 0; i < V; ++i) oe[i] = from_f32<T>(o[i]);
-                    *(u32x4*)((T*)dhid.base + row_of(dhid, n, oy) + lo_dhid) = raw;
+                    if (owner) *(u32x4*)((T*)dhid.base + row_of(dhid, n, oy) + lo_dhid) = raw;
 #pragma unroll
                     for (int i = 0; i < V; ++i) { const float dv = to_f32(oe[i]); va[i] = fmaf(wa, dv, va[i]); vb[i] = fmaf(wb, dv, vb[i]); }
                 }
                 if (++oy == H) {                                        // (uniform) the image is done: its last source rows, next image
-                    if (!(H2U_DBG & 1)) {
-                        finalize(cur, va);
-                        if (cur + 1 < dg.h) finalize(cur + 1, vb);
-                        if (pend) flush();
-                    }
+                    finalize(cur, va);
+                    if (cur + 1 < dg.h) finalize(cur + 1, vb);
+                    if (pend) flush();
 #pragma unroll
                     for (int i = 0; i < V; ++i) va[i] = vb[i] = 0.f;
                     cur = 0; oy = 0; n += G;
@@ -1348,9 +1349,16 @@ __global__ __launch_bounds__(512) void head2_backward_up_kernel(FrameGeo dout, F
             }
         }
     }
-    // weight-gradient partial of this (image, slice): the eight pixel columns of a wave by shuffles, the eight waves through LDS, fixed order
+    if (!owner) {                                                       // idle lanes and the other half's columns
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bs[j] = 0.f;
+#pragma unroll
+            for (int i = 0; i < V / 2; ++i) acc[j][i] = (f32x2){0.f, 0.f};
+        }
+    }
+    // weight-gradient partial of this workgroup: the eight pixel columns of a wave by shuffles, the four waves through LDS, fixed order
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (H2U_DBG & 2) { if (acc[0][0][0] == 123.f && bs[0] == 1.f) partial[0] = 1.f; return; }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -1359,12 +1367,12 @@ __global__ __launch_bounds__(512) void head2_backward_up_kernel(FrameGeo dout, F
             a += __shfl_xor(a, 8); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
             acc[j][i >> 1][i & 1] = a;
         }
-        float b = bs[j];
-        b += __shfl_xor(b, 8); b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-        bs[j] = b;
+        float bsum = bs[j];
+        bsum += __shfl_xor(bsum, 8); bsum += __shfl_xor(bsum, 16); bsum += __shfl_xor(bsum, 32);
+        bs[j] = bsum;
     }
     __syncthreads();
-    float* red = s_v;                                            // [wave][j][64 channels] + [wave][8] bias sums
+    float* red = s_v;                                                   // [wave][j][64 channels] + [wave][8] bias sums
     if (lane < LPP) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -1373,23 +1381,45 @@ __global__ __launch_bounds__(512) void head2_backward_up_kernel(FrameGeo dout, F
         }
         if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[8 * 8 * CS + wv * 8 + j] = bs[j];
+            for (int j = 0; j < 8; ++j) red[4 * 8 * CS + wv * 8 + j] = bs[j];
         }
     }
     __syncthreads();
     {
-        const int j = threadIdx.x / CS, c = threadIdx.x % CS;
-        float o = 0.f;
+        const size_t blk = (size_t)grp * plan.halves + half;
+        const int c = threadIdx.x % CS;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o += red[(q * 8 + j) * CS + c];
-        partial[((size_t)grp * nh * 8 + hd * 8 + j) * 512 + cbase + c] = o;
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = threadIdx.x / CS + 4 * jj;
+            float o = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o += red[(q * 8 + j) * CS + c];
+            partial[(blk * nh * 8 + hd * 8 + j) * 512 + cbase + c] = o;
+        }
         if (cbase == 0 && threadIdx.x < 8) {
-            float b = 0.f;
+            float bsum = 0.f;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) b += red[8 * 8 * CS + q * 8 + threadIdx.x];
-            bpartial[(size_t)grp * 32 + hd * 8 + threadIdx.x] = b;
+            for (int q = 0; q < 4; ++q) bsum += red[4 * 8 * CS + q * 8 + threadIdx.x];
+            bpartial[blk * 32 + hd * 8 + threadIdx.x] = bsum;
         }
     }
+}
+// The split of a row between two workgroups (host side; the same float arithmetic as bilin_coef: one product, truncation, clamp).
+static bool h2u_plan(int W, int ws, float sx, H2UPlan& p) {
+    if (W > 64 || ws > 32 || W < 1 || ws < 1) return false;
+    int x0[64];
+    for (int ox = 0; ox < W; ++ox) { int v = (int)(sx * (float)ox); x0[ox] = v > ws - 1 ? ws - 1 : v; }
+    if (W <= 32 && ws <= 16) { p.halves = 1; p.h[0] = p.h[1] = H2UHalf{0, W, 0, W, 0, ws}; return true; }
+    const int S = ws / 2;                                               // source columns [0, S) and [S, ws)
+    if (S < 1 || S > 16 || ws - S > 16) return false;
+    int hiL = -1, loR = W;
+    for (int ox = 0; ox < W; ++ox) { if (x0[ox] <= S - 1) hiL = ox; if (x0[ox] >= S - 1 && ox < loR) loR = ox; }
+    if (hiL + 1 > 32 || W - loR > 32 || loR > hiL + 1) return false;
+    const int P = (loR + hiL + 1) / 2;                                  // ownership boundary inside the overlap
+    p.halves = 2;
+    p.h[0] = H2UHalf{0, hiL + 1, 0, P, 0, S};
+    p.h[1] = H2UHalf{loR, W - loR, P, W, S, ws - S};
+    return true;
 }
 template <typename T>
 static int head2_backward_up_t(const dbx_view* dout, const dbx_view* hid, const float* const* w2, const int32_t* k, int nh, const dbx_view* dhid,
@@ -1398,8 +1428,8 @@ static int head2_backward_up_t(const dbx_view* dout, const dbx_view* hid, const 
     VIEW_VEC_CHECK(T, dg, "head2_backward_up d_g44");
     DBX_REQUIRE(dg->n == hid->n && dg->c == hid->c, "head2_backward_up: d_g44 has the hidden map's batch and channels");
     const float sy = ac_scale(dg->h, hid->h), sx = ac_scale(dg->w, hid->w);
-    bool fused = sizeof(T) == 2 && hid->w <= 64 && dg->w <= 32 && sy > 0.f && sy < 1.f && sx > 0.45f && sx < 1.f && hid->c % 64 == 0 &&
-                 hid->n <= head2_wgrad_blocks(hid->n * hid->h);
+    H2UPlan plan;
+    bool fused = sizeof(T) == 2 && sy > 0.f && sy < 1.f && sx > 0.45f && sx < 1.f && hid->c % 64 == 0 && hid->h >= 2 && h2u_plan(hid->w, dg->w, sx, plan);
     if (const char* e = getenv("DBX_HEAD2_UP")) fused = fused && atoi(e) != 0;
     if (!fused) {                                                       // the two passes
         const int rc = head2_wgrad_t<T>(dout, hid, k, nh, dw, db, scratch, s, w2, dhid, mask, mask_ld, use_hash, drop_seed);
@@ -1420,28 +1450,25 @@ static int head2_backward_up_t(const dbx_view* dout, const dbx_view* hid, const 
             ha.w2[i] = i < nh ? w2[i] : nullptr; ha.k[i] = i < nh ? k[i] : 0;
             if (i < nh) DBX_REQUIRE(k[i] >= 1 && k[i] <= 8 && dw[i] && w2[i] && ((size_t)w2[i] % 16) == 0, "head2_backward_up: k in 1..8, 16-byte aligned weights");
         }
-#ifndef H2U_WGS
-#define H2U_WGS 256
-#endif
-        // one workgroup per CU (244 VGPRs x 512 threads): `groups` workgroups per channel slice, each walking every groups-th image
+        // two workgroups per CU (248 VGPRs x 256 threads): `groups` workgroups per (channel slice, half), each walking every groups-th image
         const int nsl = hid->c / 64;
-        int groups = H2U_WGS / nsl;
+        int groups = H2U_WGS / (nsl * plan.halves);
         groups = groups < 1 ? 1 : groups > hid->n ? hid->n : groups;
+        const int blocks = groups * plan.halves;                        // <= 2 n <= n h and <= 512 / nsl: inside dbx_head2_wgrad_scratch_bytes
         float* partial = (float*)scratch;
-        float* bpartial = partial + (size_t)groups * nh * 8 * 512;
-        // LDS: the ring of 2 * NB row buffers, at least the 8 x 8 x 64 + 64 floats of the final weight-gradient reduction
-        size_t smem = (size_t)2 * H2U_NB * hid->w * 64 * 4;
-        if (smem < (8 * 8 * 64 + 64) * 4) smem = (8 * 8 * 64 + 64) * 4;
+        float* bpartial = partial + (size_t)blocks * nh * 8 * 512;
+        constexpr size_t smem = (size_t)2 * H2U_NB * 32 * 64 * 4;       // the ring (>= the 4 x 8 x 64 + 32 floats of the final reduction)
+        static_assert(smem >= (4 * 8 * 64 + 32) * 4 && 2 * smem + 4096 <= 160 * 1024, "LDS budget of two workgroups per CU");
         static bool attr_set = false;
         if (!attr_set) {
-            DBX_HIP(hipFuncSetAttribute((const void*)head2_backward_up_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * H2U_NB * 64 * 64 * 4));
+            DBX_HIP(hipFuncSetAttribute((const void*)head2_backward_up_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             attr_set = true;
         }
-        hipLaunchKernelGGL(head2_backward_up_kernel<T>, dim3(groups * nsl), dim3(512), smem, s, make_geo<T>(dout), make_geo<T>(hid), make_geo<T>(dhid),
-                           make_geo<T>(dg), nh, dout->c / nh, ha, partial, bpartial, mask, mask_ld, use_hash, drop_seed, sy, sx);
+        hipLaunchKernelGGL(head2_backward_up_kernel<T>, dim3(blocks * nsl), dim3(256), smem, s, make_geo<T>(dout), make_geo<T>(hid), make_geo<T>(dhid),
+                           make_geo<T>(dg), nh, dout->c / nh, ha, partial, bpartial, mask, mask_ld, use_hash, drop_seed, sy, sx, plan);
         DBX_LAUNCH_CHECK();
         const int total = nh * 8 * 512 + nh * 8;
-        hipLaunchKernelGGL(head2_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, s, partial, bpartial, groups, nh, o);
+        hipLaunchKernelGGL(head2_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, s, partial, bpartial, blocks, nh, o);
         DBX_LAUNCH_CHECK();
     }
     return DBX_OK;

@@ -433,11 +433,12 @@ def test_head2_backward_fused_equals_separate_calls(dtn, drop):
 
 @pytest.mark.parametrize('dtn', ['bf16', 'f16', 'f32'])
 @pytest.mark.parametrize('drop', ['hash', 'mask', 'none'])
-@pytest.mark.parametrize('geom', [(3, 60, 60, 30, 30), (2, 23, 37, 12, 19), (2, 10, 64, 9, 32), (2, 10, 64, 9, 33), (1, 12, 70, 6, 35)])
+@pytest.mark.parametrize('geom', [(3, 60, 60, 30, 30), (2, 23, 37, 12, 19), (2, 9, 24, 5, 12), (11, 7, 31, 4, 16), (2, 10, 64, 9, 32), (2, 10, 64, 9, 33), (1, 12, 70, 6, 35)])
 def test_head2_backward_up_equals_backward_then_transposed_upsampling(geom, drop, dtn):
     """dbx_head2_backward_up == dbx_head2_backward followed by dbx_upsample_bilinear_bwd (no gate): d_hid and d_g44 bit for bit, the
-    weight/bias gradients up to the order of the fp32 sums (per image instead of per pixel range); repeatable bit for bit.  f32 and maps
-    wider than 64 pixels take the two passes inside the entry point."""
+    weight/bias gradients up to the order of the fp32 sums; repeatable bit for bit.  60x60 -> 30x30 and 23x37 -> 12x19 run as two
+    half-row workgroups per slice, 9x24 -> 5x12 and 7x31 -> 4x16 as one; f32, the 64-wide maps (a half would be 33 columns) and the
+    70-wide one take the two passes inside the entry point."""
     L = _lib.lib()
     dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
     n, h, w, hs, ws = geom

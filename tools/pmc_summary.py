@@ -1,4 +1,4 @@
-import sqlite3, sys, re, collections
+import sqlite3, sys, re, collections, os
 db = sqlite3.connect(sys.argv[1]); cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
 def T(p): return [t for t in tabs if t.startswith(p)][0]
@@ -14,5 +14,5 @@ except Exception as ex:
 by = collections.defaultdict(dict)
 for k, n, v, c in rows: by[re.sub(r'\(.*\)$', '', k)][n] = v
 for k, d in by.items():
-    if 'conv' in k or 'wgrad' in k:
+    if (re.search(os.environ['PMC_FILTER'], k) if os.environ.get('PMC_FILTER') else ('conv' in k or 'wgrad' in k)):
         print(k[:100]); [print('    %-32s %16.1f' % (n, v)) for n, v in sorted(d.items())]
