@@ -1144,7 +1144,8 @@ extern "C" int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const db
 // to an LDS ring and NB rows at a time are reduced over x and stored.  The two halves of a row overlap by the few destination
 // columns both sides' source columns interpolate from (their d_hid is computed twice, stored and accumulated by the owner only), so
 // the halves are independent workgroups: 256 threads, two per CU -- one's barriers and x reductions run under the other's streaming
-// (one 512-thread workgroup per CU lost ~25 % to them).  Coefficients, order of accumulation (y before x, ascending) and rounding
+// (3 % faster than one 512-thread workgroup per CU walking whole rows; what the kernel's speed hangs on is in the comments at the row
+// loop: unconditional prefetch loads, scalar row bases, a branch-free body).  Coefficients, order of accumulation (y before x, ascending) and rounding
 // points (d_hid rounded to T first) are those of upsample_bwd_walk_kernel; d_hid is bitwise head2_dgrad_kernel's.  The
 // weight-gradient partials are one block per workgroup (fixed order), combined by head2_wgrad_reduce_kernel as before.
 #ifndef H2U_D
