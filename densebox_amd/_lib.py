@@ -120,6 +120,7 @@ SIGNATURES = {
     'dbx_nms': (C.c_int, [_VP, _I32, _I32, _D, _VP, _VP, _VP]),
 }
 
+ABI_VERSION = 3          # include/densebox_hip.h DBX_ABI_VERSION this binding was written against
 _lib = None
 MISSING = []
 
@@ -139,6 +140,9 @@ def lib():
                 continue
             fn.restype = res
             fn.argtypes = args
+        if 'dbx_version' not in MISSING and L.dbx_version() != ABI_VERSION:
+            raise RuntimeError('libdensebox_hip.so at %s has ABI version %d, this binding needs %d (struct layouts / scratch '
+                               'contracts differ): rebuild it' % (LIB_PATH, L.dbx_version(), ABI_VERSION))
         _lib = L
     return _lib
 

@@ -13,7 +13,7 @@ void dbx_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* dbx_last_error(void) { return g_err; }
-extern "C" int dbx_version(void) { return 1; }
+extern "C" int dbx_version(void) { return DBX_ABI_VERSION; }
 extern "C" int dbx_device_arch(int device) {
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) != hipSuccess) { dbx_set_error("hipGetDeviceProperties failed"); return DBX_ERR_HIP; }
@@ -1460,10 +1460,10 @@ static int head2_backward_up_t(const dbx_view* dout, const dbx_view* hid, const 
         float* bpartial = partial + (size_t)blocks * nh * 8 * 512;
         constexpr size_t smem = (size_t)2 * H2U_NB * 32 * 64 * 4;       // the ring (>= the 4 x 8 x 64 + 32 floats of the final reduction)
         static_assert(smem >= (4 * 8 * 64 + 32) * 4 && 2 * smem + 4096 <= 160 * 1024, "LDS budget of two workgroups per CU");
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DbxDevOnce attr_once; int attr_dev = 0;
+        if (attr_once.pending(&attr_dev)) {
             DBX_HIP(hipFuncSetAttribute((const void*)head2_backward_up_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            attr_set = true;
+            attr_once.mark(attr_dev);
         }
         hipLaunchKernelGGL(head2_backward_up_kernel<T>, dim3(blocks * nsl), dim3(256), smem, s, make_geo<T>(dout), make_geo<T>(hid), make_geo<T>(dhid),
                            make_geo<T>(dg), nh, dout->c / nh, ha, partial, bpartial, mask, mask_ld, use_hash, drop_seed, sy, sx, plan);

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/densebox_hip.h"
 
@@ -42,6 +43,19 @@ void dbx_set_error(const char* fmt, ...);
             return DBX_ERR_ARG;                                                               \
         }                                                                                     \
     } while (0)
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies per DEVICE: one "done" bit per device ordinal, so a process that drives
+// several GPUs sets it on each of them (a single process-wide flag made the first launch on a second device fail); thread-safe.
+struct DbxDevOnce {
+    std::atomic<uint64_t> done{0};
+    bool pending(int* dev_out) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+        *dev_out = dev;
+        return !((done.load(std::memory_order_acquire) >> (dev & 63)) & 1ull);
+    }
+    void mark(int dev) { done.fetch_or(1ull << (dev & 63), std::memory_order_release); }
+};
 
 static inline int dbx_esize(int dtype) { return dtype == DBX_F32 ? 4 : 2; }
 

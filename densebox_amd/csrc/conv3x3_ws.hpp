@@ -478,10 +478,10 @@ static int launch_conv_ws(const ConvArgs& a, int n, int h, int xpad, hipStream_t
     if constexpr (sizeof(T) == 2) {
         constexpr int smem = 2 * ws::pieces(WM, KS) * 1024 + ws::D * (256 / WM) * 32;
         static_assert(smem <= 160 * 1024, "LDS budget");
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DbxDevOnce attr_once; int attr_dev = 0;
+        if (attr_once.pending(&attr_dev)) {
             DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<T, WM, KS, EPIK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
+            attr_once.mark(attr_dev);
         }
         static int ncu = 0;
         if (!ncu) {

@@ -1282,11 +1282,11 @@ extern "C" int64_t dbx_conv_packed_elems(const dbx_conv_desc* d) {
 template <typename T, int BM, int BN, int WM, int WN, bool SMALLC>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     constexpr int smem = 2 * (BM + BN) * 128;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DbxDevOnce attr_once; int attr_dev = 0;
+    if (attr_once.pending(&attr_dev)) {
         DBX_HIP(hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BM, BN, WM, WN, SMALLC>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, WM, WN, SMALLC>), dim3(a.nblocks), dim3(256), smem, s, a);
     DBX_LAUNCH_CHECK();
@@ -1296,11 +1296,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
 template <typename T, int BM, int BN, int BKB, int STAGES, int WM, int WN>
 static int launch_conv_dma(const ConvArgs& a, hipStream_t s) {
     constexpr int smem = STAGES * (BM + BN) * BKB;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DbxDevOnce attr_once; int attr_dev = 0;
+    if (attr_once.pending(&attr_dev)) {
         DBX_HIP(hipFuncSetAttribute((const void*)conv_igemm_dma_kernel<T, BM, BN, BKB, STAGES, WM, WN>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     static int ncu = 0;
     if (!ncu) {
@@ -1318,11 +1318,11 @@ template <typename T, int BM, int BN, int STAGES, int WM, int WN>
 static int launch_conv_band(const ConvArgs& a, hipStream_t s) {
     constexpr int smem = STAGES * ((BM + 16) / 16 + 3 * BN / 16) * 1024;
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DbxDevOnce attr_once; int attr_dev = 0;
+    if (attr_once.pending(&attr_dev)) {
         DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_band_kernel<T, BM, BN, STAGES, WM, WN>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     hipLaunchKernelGGL((conv3x3_band_kernel<T, BM, BN, STAGES, WM, WN>), dim3(a.nblocks), dim3(512), smem, s, a);
     DBX_LAUNCH_CHECK();
@@ -1357,10 +1357,10 @@ static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s
     if constexpr (sizeof(T) == 2) {
         constexpr int smem = 64 * 1168 + 2 * (340 * 128 + 1024);
         static_assert(smem <= 160 * 1024, "LDS budget");
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DbxDevOnce attr_once; int attr_dev = 0;
+        if (attr_once.pending(&attr_dev)) {
             DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_c64_kernel<T, POOL, WG1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
+            attr_once.mark(attr_dev);
         }
         static int ncu = 0;
         if (!ncu) {

@@ -1693,20 +1693,20 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     if (p.wide2) {
         if constexpr (sizeof(T) == 2) {
             constexpr int smem = 4 * 2 * 32 * 512;
-            static bool attr_set = false;
-            if (!attr_set) {
+            static DbxDevOnce attr_once; int attr_dev = 0;
+            if (attr_once.pending(&attr_dev)) {
                 DBX_HIP(hipFuncSetAttribute((const void*)wgrad_wide2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                attr_set = true;
+                attr_once.mark(attr_dev);
             }
             hipLaunchKernelGGL((wgrad_wide2_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a);
         }
     } else if (p.all9) {
         if constexpr (sizeof(T) == 2) {
             constexpr int smem = 3 * (64 * 256 + 3 * 72 * 128);
-            static bool attr_set = false;
-            if (!attr_set) {
+            static DbxDevOnce attr_once; int attr_dev = 0;
+            if (attr_once.pending(&attr_dev)) {
                 DBX_HIP(hipFuncSetAttribute((const void*)wgrad_all9_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                attr_set = true;
+                attr_once.mark(attr_dev);
             }
             hipLaunchKernelGGL((wgrad_all9_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a);
         }
@@ -1716,14 +1716,14 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
         if constexpr (sizeof(T) == 2)
             {
                 constexpr int smem = 2 * (32 * 128 + 3 * 36 * 128);
-                static bool attr_set = false;
+                static DbxDevOnce attr_once; int attr_dev = 0;
                 static int pad = 0;                                   // lab builds: DBX_WGRAD_LDSPAD = extra dynamic LDS (occupancy experiments)
-                if (!attr_set) {
+                if (attr_once.pending(&attr_dev)) {
 #ifdef DBX_LAB
                     const char* e = getenv("DBX_WGRAD_LDSPAD"); pad = e ? atoi(e) : 0;
 #endif
                     DBX_HIP(hipFuncSetAttribute((const void*)wgrad3x3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem + pad));
-                    attr_set = true;
+                    attr_once.mark(attr_dev);
                 }
                 if (p.strip) {
                     constexpr int smem2 = 2 * 32 * 128 + 4 * 36 * 128;
@@ -1735,20 +1735,20 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     } else if (p.row3) {
         if constexpr (sizeof(T) == 2) {
             constexpr int smem = 2 * (64 * 256 + 68 * 256);
-            static bool attr_set = false;
-            if (!attr_set) {
+            static DbxDevOnce attr_once; int attr_dev = 0;
+            if (attr_once.pending(&attr_dev)) {
                 DBX_HIP(hipFuncSetAttribute((const void*)wgrad_row3_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                attr_set = true;
+                attr_once.mark(attr_dev);
             }
             hipLaunchKernelGGL((wgrad_row3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * 3 * p.splits), dim3(512), smem, s, a);
         }
     } else if (p.wide) {
         if constexpr (sizeof(T) == 2) {
             constexpr int smem = 4 * 64 * 512;
-            static bool attr_set = false;
-            if (!attr_set) {
+            static DbxDevOnce attr_once; int attr_dev = 0;
+            if (attr_once.pending(&attr_dev)) {
                 DBX_HIP(hipFuncSetAttribute((const void*)wgrad_wide_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                attr_set = true;
+                attr_once.mark(attr_dev);
             }
             hipLaunchKernelGGL((wgrad_wide_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.taps * p.splits), dim3(512), smem, s, a);
         }

@@ -237,10 +237,10 @@ extern "C" int dbx_refine_backward(const float* d_refine, const float* landmark,
     const int64_t tot_g = (int64_t)n * oh * ow;
     hipLaunchKernelGGL(refine_up_t_kernel, dim3((unsigned)((tot_g + 255) / 256)), dim3(256), 0, s, d_refine, n, h, w, g, oh, ow, rf_scale(oh, h), rf_scale(ow, w));
     DBX_LAUNCH_CHECK();
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DbxDevOnce attr_once; int attr_dev = 0;
+    if (attr_once.pending(&attr_dev)) {
         DBX_HIP(hipFuncSetAttribute((const void*)refine_g1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     hipLaunchKernelGGL(refine_g1_kernel, dim3(n * RSPLIT), dim3(256), lds, s, landmark, score, h, w, g, partial);
     DBX_LAUNCH_CHECK();

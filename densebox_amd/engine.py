@@ -66,8 +66,16 @@ class Buf:
 class Plan:
     """Workspace layout for one (N, H, W, dtype, train) configuration."""
 
+    @staticmethod
+    def env_flags():
+        """The environment switches that decide which buffers a plan holds (part of the plan cache key)."""
+        return tuple(os.environ.get(k, '1') != '0' for k in ('DBX_LIN_BWD', 'DBX_REFINE_LINEAR', 'DBX_POOL_IDX'))
+
     def __init__(self, kind, n, h, w, dtype_id, device, train):
         self.kind, self.n, self.h, self.w, self.dtype_id, self.train = kind, n, h, w, dtype_id, train
+        self.flags = Plan.env_flags()
+        lin_bwd, lin_refine, use_idx = self.flags
+        lin_bwd = lin_bwd and dtype_id != _lib.F32
         es = _lib.ESIZE[dtype_id]
         self.cin0 = 16 // es                      # conv1_1 input channels padded to one 16-byte chunk
         # refine branch (cat(landmarks, score) -> pool -> 3x3 -> 5x5 -> bilinear -> 1x1; 61 MMAC per patch) runs in the compute type.
@@ -84,14 +92,22 @@ class Plan:
         def add(name, hh, ww, c, pad=1, dt=None):
             B[name] = Buf(name, n, hh, ww, c, pad, dtype_id if dt is None else dt)
         add('x0', h, w, self.cin0)
-        add('a11', h, w, 64); add('a12', h, w, 64); add('p1', h2, w2, 64)
+        # conv1_2's full-resolution output is only written when its pooling is NOT fused (fp32 / odd sizes) or when a backward pass
+        # will re-read it (training without the arg-max nibbles); otherwise the name aliases a11 (never written: the fused call skips
+        # the full map) instead of holding 480 MB at batch 64
+        self.a12_alias = es == 2 and h % 2 == 0 and w % 2 == 0 and (not train or use_idx)
+        add('a11', h, w, 64)
+        if not self.a12_alias:
+            add('a12', h, w, 64)
+        add('p1', h2, w2, 64)
         add('a21', h2, w2, 128); add('a22', h2, w2, 128); add('p2', h4, w4, 128)
         add('a31', h4, w4, 256); add('a32', h4, w4, 256)
         add('fusion', h4, w4, 768)                # [0:512) = upsampled conv4_4, [512:768) = conv3_4 (concat for free)
         add('p3', h8, w8, 256)
         add('a41', h8, w8, 512); add('a42', h8, w8, 512); add('a43', h8, w8, 512); add('a44', h8, w8, 512)
         add('hid', h4, w4, 512 * nh, pad=0)
-        if kind != 'DenseBox':
+        rf_convs = kind != 'DenseBox' and train and not lin_refine      # the three refine convs on the MFMA kernels (A/B, tests)
+        if rf_convs:
             # frames chosen so that each conv's (dz, x) pair is congruent for the weight gradient AND dz has the
             # k-1 pixel frame its data gradient needs: rf_p(+1) ~ d_rf_1(+2), rf_1(+2) ~ d_rf_2(+4)
             add('rf_in', h4, w4, self.crf, pad=0, dt=self.rdt)
@@ -101,15 +117,17 @@ class Plan:
             add('rf_u', h4, w4, 64, pad=0, dt=self.rdt)
         if train:
             # gradients (dZ = dL/d pre-activation) live in frames congruent to the matching activation
-            for nm in ('a11', 'a12', 'a21', 'a22', 'a31', 'a32', 'a41', 'a42', 'a43', 'a44'):
+            for nm in ('a11', 'a21', 'a22', 'a31', 'a32', 'a41', 'a42', 'a43', 'a44'):
                 add('d_' + nm, B[nm].h, B[nm].w, B[nm].c)
+            add('d_a12', h, w, 64)
             add('d_c34', h4, w4, 256)
-            add('d_ups', h4, w4, 512, pad=0)
+            if not lin_bwd:
+                add('d_ups', h4, w4, 512, pad=0)          # (the heads' backward by linearity never forms it)
             add('d_p1', h2, w2, 64, pad=0); add('d_p2', h4, w4, 128, pad=0); add('d_p3', h8, w8, 256, pad=0)
             add('d_hid', h4, w4, 512 * nh, pad=1)         # congruent with 'fusion'
             add('d_g44', h8, w8, 512 * nh, pad=1)         # up^T(d_hid): the hidden gradient on conv4_4's grid, congruent with 'a44'
             add('d_out', h4, w4, self.crf * nh, pad=0)    # dL/d(head outputs), one crf-channel slot per head
-            if kind != 'DenseBox':
+            if rf_convs:
                 add('d_rfo', h4, w4, self.crf, pad=0)
                 add('d_rf_u', h4, w4, 64, pad=0)
                 add('d_rf_2', h8 - 6, w8 - 6, 64, pad=4)
@@ -138,6 +156,8 @@ class Plan:
         assert base % 256 == 0
         for b in B.values():
             b.base = base + b.off
+        if self.a12_alias:
+            B['a12'] = B['a11']
         self.B = B
 
 
@@ -188,8 +208,8 @@ class Engine:
         return t
 
     def _pack(self, dt, mode, w, rows_pad, cin_pad, kh, kw, out=None, row_off=0, k_off=0):
-        # (row_off / k_off may be negative: elements that land outside [0, rows_pad) x [0, cin_pad) are skipped -- channel slices)
-        """fp32 OIHW parameter -> packed compute-dtype matrix [rows_pad][ktot]."""
+        """fp32 OIHW parameter -> packed compute-dtype matrix [rows_pad][ktot].
+        (row_off / k_off may be negative: elements that land outside [0, rows_pad) x [0, cin_pad) are skipped -- channel slices)"""
         d = ConvDesc(dt, kh, kw, 0, cin_pad, rows_pad, 0, 0)
         elems = self.L.dbx_conv_packed_elems(C.byref(d))
         if out is None:
@@ -285,7 +305,7 @@ class Engine:
                 r = self.conv_plan(dt, B['d_hid'].view(), B['d_c34'].view(), 1, 1, 0, 512 * nh, 256, _lib.EPI_GATE)[2]
             elif which in ('ba', 'bc'):
                 r = False
-            elif 'd_hid' in B and dt != _lib.F32:
+            elif 'd_hid' in B and 'd_ups' in B and dt != _lib.F32:
                 dv = B['d_ups'].view()
                 both = View(dv.ptr, dv.n, dv.h, dv.w, dv.pad, 768, 0, 768)      # both destinations' couts, for planning only
                 r = self.conv_plan(dt, B['d_hid'].view(), both, 1, 1, 0, 512 * nh, 768, 0)[2]
@@ -302,10 +322,11 @@ class Engine:
         for stem, cin, cout in _BACKBONE:
             self._w_fwd(dt, stem, P.cin0 if cin == 3 else cin, max(64, cout), frag=self._frag(P, dt, stem, 'f'))
             self._bias([stem], max(64, cout))
-        self._w_heads1(dt, frag=train and self._frag_heads(P, dt, 'f'))
-        self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
-        self._w_heads2(dt)
-        self._bias(['conv5_2_' + s_ for s_, _ in heads], 64)
+        if train:             # (eval runs the folded heads: _w_heads_folded, packed on its own)
+            self._w_heads1(dt, frag=self._frag_heads(P, dt, 'f'))
+            self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
+            self._w_heads2(dt)
+            self._bias(['conv5_2_' + s_ for s_, _ in heads], 64)
         # the refine branch runs from its fp32 parameters (folded 7x7 conv, dbx_refine_backward) unless DBX_REFINE_LINEAR=0 in training
         rf_convs = kind != 'DenseBox' and train and os.environ.get('DBX_REFINE_LINEAR', '1') == '0'
         if rf_convs:
@@ -455,7 +476,7 @@ class Engine:
                 dict(self._tables))
 
     def plan(self, n, h, w, dt, device, train):
-        key = (n, h, w, dt, train)
+        key = (n, h, w, dt, train, Plan.env_flags())
         p = self.plans.get(key)
         if p is None:
             p = Plan(self.kind, n, h, w, dt, device, train)
@@ -559,6 +580,7 @@ class Engine:
                 prof.append({'kernel': self.conv_plan(dt, a11v, a12v, 3, 3, 1, 64, 64, RELU)[1],
                              'flops': 2.0 * a12v.n * a12v.h * a12v.w * 9 * 64 * 64, 'start': ev0, 'end': ev1})
         else:
+            assert not P.a12_alias, 'conv1_2 + pool1 not fusable on a plan without a full-resolution conv1_2 map'
             conv3('conv1_2_1', 'a11', 'a12', 64, 64)
             pool(a12v, p1v, 'a12')
         conv3('conv2_1_1', 'p1', 'a21', 64, 128)
@@ -853,7 +875,9 @@ class Engine:
             if sink is not None:
                 sink.ready(pn)
             override = {'landmark': o_lm, 'det': o_det}
-            P.refine_fwd = None
+            # (P.refine_fwd stays: the forward pass resets it, and a second backward over the same forward -- retain_graph -- re-runs this path)
+        elif kind != 'DenseBox' and os.environ.get('DBX_REFINE_LINEAR', '1') != '0':
+            raise RuntimeError('densebox_amd: backward of the refine branch without its forward state (no training-mode forward on this plan)')
         elif kind != 'DenseBox':
             d_rfo = B['d_rfo'].view()
             check(L.dbx_nchw_to_framed(dt, ptr(gout('refine', 1)), 1, C.byref(d_rfo), s))

@@ -36,6 +36,12 @@ enum dbx_status {
 enum dbx_dtype { DBX_F16 = 0, DBX_BF16 = 1, DBX_F32 = 2 };
 
 const char* dbx_last_error(void);
+/* ABI version of the header a caller was compiled against; dbx_version() returns the library's.  Bumped whenever a struct layout,
+ * an argument list or a scratch-size contract changes (a binding must refuse a library whose version differs):
+ *   2  (round 3) dbx_loss_forward_backward's scratch grew from n doubles to dbx_loss_scratch_bytes(n) (mask planes + partial sums);
+ *      the dbx_pack_multi job record's former pad field became rows_lim
+ *   3  (round 4) fused entry points added (see the round-4 section below); nothing removed */
+#define DBX_ABI_VERSION 3
 int dbx_version(void);
 /* device sanity: returns gfx arch number (950) of `device`, or <0 */
 int dbx_device_arch(int device);

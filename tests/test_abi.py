@@ -16,6 +16,10 @@ def _header_functions():
     return sorted(set(re.findall(r'\b(dbx_[a-z0-9_]+)\s*\(', src)))
 
 
+def _header_abi_version():
+    return int(re.search(r'#define\s+DBX_ABI_VERSION\s+(\d+)', open(HEADER).read()).group(1))
+
+
 def test_library_builds_and_exports_every_declared_symbol():
     from densebox_amd import _build, _lib
     lib = _build.build(verbose=False)
@@ -28,7 +32,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     out = subprocess.run(['nm', '-D', '--defined-only', lib], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (dbx_[a-z0-9_]+)', out))
     assert set(declared) <= exported, set(declared) - exported
-    assert L.dbx_version() == 1
+    assert L.dbx_version() == _lib.ABI_VERSION == _header_abi_version()
     assert isinstance(L.dbx_last_error(), bytes)
 
 
