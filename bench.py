@@ -35,7 +35,8 @@ FWD_GFLOP = {'DenseBox': 41.98, 'DenseBoxLM': 44.95, 'DenseBoxLMLOC': 47.81}
 STEP_GFLOP = {'DenseBox': 125.7, 'DenseBoxLM': 134.6, 'DenseBoxLMLOC': 143.2}
 MFMA_PEAK_TF = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}     # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = 'r03_pmc_traffic.json'
+PMC_FILE = 'r04_pmc_traffic.json'
+ERR_FILES = ('r04_lowprec_errors.json', 'r03_lowprec_errors.json')
 
 
 def conv_flops(eng_calls):
@@ -95,6 +96,22 @@ def cpu_baseline(kind, seconds=20.0):
             if e >= budget or k >= max_it:
                 return e / k, k
     cases = {}
+    # one `DenseBox` (score + bbox heads) training step at N = 8, same oracle
+    n8 = 8
+    net8 = D.DenseBox(synth.vgg19_standin(seed=0))
+    synth.fill_params_(net8, 11)
+    P8 = {k: v.detach().clone().requires_grad_(True) for k, v in net8.named_parameters()}
+    x8, bbox8, vert8, lab8 = synth.synth_batch(n8, seed=7, neg_frac=0.0)
+    _, half8 = LB.neg_counts(int(LB.positive_count(bbox8, None).sum()), n8)
+    rn8 = synth.synth_rand_neg_indices(n8, half8, seed=1).numpy()
+
+    def step8():
+        for p in P8.values():
+            p.grad = None
+        res = O.loss_step('DenseBox', O.forward('DenseBox', P8, x8), bbox8.numpy(), vert8.numpy(), None, rand_neg=rn8, lm_rand_neg=None)
+        res['loss'].backward()
+    sec, k = timed(step8, 6.0, 6)
+    cases['train_step_DenseBox_N8_240x240'] = {'patches_per_s': round(n8 / sec, 3), 'iterations': k}
     with torch.no_grad():
         for nn_ in (1, 8):
             xf = synth.synth_batch(nn_, seed=5, neg_frac=0.0)[0]
@@ -112,6 +129,23 @@ def cpu_baseline(kind, seconds=20.0):
             cases['inference_DenseBox_%s' % name] = {'img_per_s': round(1.0 / sec, 3), 'iterations': k}
     out['cases'] = cases
     return out
+
+
+def achieved_tolerance(dtype):
+    """Forward error of this compute dtype against the reference-captured fixtures, from the committed summary of
+    tools/gpu_lowprec_err.py (newest round present): worst map's max |hip - ref| / max(1, max|ref|) and worst per-map RMS.
+    north_star asks for 1e-3: fp32 meets it in max norm, f16 in RMS only (13 stacked layers rounding to 11 bits), bf16 in neither
+    -- the line carries the numbers so that `dtype` is never read as "1e-3 parity at f16"."""
+    for fn in ERR_FILES:
+        path = os.path.join(ROOT, 'profiles', fn)
+        if os.path.exists(path):
+            maps = {k: v for k, v in json.load(open(path))['maps'].items() if k.split('/')[1] == dtype}
+            if maps:
+                return {'max': float('%.3g' % max(v['rel'] for v in maps.values())),
+                        'rms': float('%.3g' % max(v['rms_rel'] for v in maps.values())),
+                        'of': 'max(1, max|reference map|), worst of %d output maps, fp32 PyTorch-CPU reference fixtures' % len(maps),
+                        'north_star': 1e-3, 'source': 'profiles/' + fn}
+    return None
 
 
 def csrc_hash():
@@ -155,7 +189,8 @@ def inference(kind, dev):
     net = net.to(dev).eval()
     net.compute_dtype = 'f16'
     res = {}
-    for name, (h, w, K) in (('512x512', (512, 512, 10)), ('1920x1080', (1080, 1920, 10)), ('1920x1080_top1000', (1080, 1920, 1000))):
+    for name, (h, w, K) in (('512x512', (512, 512, 10)), ('1920x1080', (1080, 1920, 10)), ('1920x1080_top100', (1080, 1920, 100)),
+                            ('1920x1080_top1000', (1080, 1920, 1000))):
         x = synth.synth_images(1, h, w, seed=1).to(dev)
         for _ in range(3):
             net.detect(x, K=K, nms_thresh=0.4)
@@ -346,7 +381,8 @@ def main():
         out = {
             'metric': 'training patches/sec (240x240)', 'value': round(value, 1), 'unit': 'patches/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'tolerance': achieved_tolerance(args.dtype), 'data': 'synthetic',
             'config': {'workload': 'full training step (fwd + fused dense loss w/ hard-negative mining + bwd + grad '
                                    'all-reduce + SGD) of %s on 240x240 patches' % kind,
                        'net': kind, 'batch_per_gpu': n, 'global_batch': n * world, 'patch': '240x240',

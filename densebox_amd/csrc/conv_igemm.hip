@@ -525,6 +525,25 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
 // 3 x 32 MFMAs per wave per barrier: 32-53 % fewer bytes through the L2 -> LDS path per FLOP than one-tap-per-stage
 // (the measured limiter of v2), and a third of the barriers.  Pieces (1 KiB = 16 rows x 64 B) are dealt round-robin to
 // the 8 waves; the source-side XOR swizzle and the counted-vmcnt ring are as in v2.
+#ifndef BAND_ABL                     // lab builds only (tools/band_lab.hip): ablation bits, see the stage loop
+#define BAND_ABL 0
+#endif
+#ifndef BAND_DPP                     // 1: the kx = 1, 2 pixel fragments are DPP row shifts of the kx = 0 fragments (no LDS reads for them)
+#define BAND_DPP 0
+#endif
+// B-operand fragment (lane = 16 g + pixel) shifted by N pixels: lanes 0 .. 15-N of every 16-lane row take lanes N .. 15 of `cur`,
+// lanes 16-N .. 15 take lanes 0 .. N-1 of `nxt` (the fragment of the next 16 pixels): two v_mov_b32_dpp per register
+template <int N>
+__device__ __forceinline__ u32x4 frag_shift_px(const u32x4& cur, const u32x4& nxt) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)nxt[i], 0x110 + (16 - N), 0xf, 0xf, false);     // row_shr:(16-N)
+        r[i] = (unsigned)__builtin_amdgcn_update_dpp(t, (int)cur[i], 0x100 + N, 0xf, 0xf, false);         // row_shl:N
+    }
+    return r;
+}
+
 template <typename T, int BM, int BN, int STAGES, int WM, int WN>
 __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
     constexpr int BKB = 64, AR = BM + 16;
@@ -589,6 +608,8 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
         char* sbase = smem + is_stage * STAGE;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
+            if ((BAND_ABL & 1) && is_a[i]) continue;
+            if ((BAND_ABL & 2) && !is_a[i]) continue;
             if (i < L_LO || extra)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (is_a[i] ? aoff : boff)),
                                                  (__attribute__((address_space(3))) void*)(sbase + (wave + 8 * i) * 1024), 16, 0, 0);
@@ -617,6 +638,9 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
     for (int d = 0; d < DEPTH; ++d)
         if (d < nk) issue();
     int stage = 0;
+#if (BAND_ABL & 8)
+    u32x4 abl_w[NI], abl_x[MI];
+#endif
     for (int ks = 0; ks < nk; ++ks) {
         const int younger = nk - 1 - ks;
         // counted wait: my loads of this stage are done once only `min(younger, DEPTH-1)` stages of mine are outstanding
@@ -632,13 +656,62 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         if (ks + DEPTH < nk) issue();
         const char* Sb = smem + stage * STAGE;
+#if (BAND_ABL & 8)
+        {   // ablation: no fragment reads -- the MFMAs of every stage run on fragments read once from the first stage
+            static_assert(true, "");
+            if (ks == 0) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) abl_w[ni] = *(const u32x4*)(Sb + offB + ni * 16 * BKB);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) abl_x[mi] = *(const u32x4*)(Sb + offA[0] + mi * 16 * BKB);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) Mma<T>::run(abl_w[ni], abl_x[mi], acc[ni][mi]);
+            stage = stage == STAGES - 1 ? 0 : stage + 1;
+            continue;
+        }
+#endif
+#if BAND_DPP
+        {
+            // ONE read of the pixel band per stage (MI + 1 fragments at row shift 0); the kx = 1, 2 operands are lane shifts of it
+            u32x4 wq[3][NI], bf[MI + 1], s1[MI + 1];
+            auto rdw = [&](int kx) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) wq[kx][ni] = *(const u32x4*)(Sb + offB + kx * BN * BKB + ni * 16 * BKB);
+            };
+            auto mmx = [&](int kx, u32x4 (&x)[MI + 1]) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) Mma<T>::run(wq[kx][ni], x[mi], acc[ni][mi]);
+            };
+            rdw(0);
+#pragma unroll
+            for (int mi = 0; mi <= MI; ++mi) bf[mi] = *(const u32x4*)(Sb + offA[0] + mi * 16 * BKB);
+            rdw(1);
+#pragma unroll
+            for (int mi = 0; mi <= MI; ++mi) s1[mi] = frag_shift_px<1>(bf[mi], bf[mi < MI ? mi + 1 : mi]);
+            mmx(0, bf);
+            rdw(2);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) bf[mi] = frag_shift_px<1>(s1[mi], s1[mi + 1]);
+            mmx(1, s1);
+            mmx(2, bf);
+            stage = stage == STAGES - 1 ? 0 : stage + 1;
+            continue;
+        }
+#endif
         // software pipeline over the three taps: the fragments of tap kx+1 are read while tap kx's MFMAs run
         u32x4 wf[2][NI], xf[2][MI];
         auto rd = [&](int kx, u32x4 (&w)[NI], u32x4 (&x)[MI]) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) w[ni] = *(const u32x4*)(Sb + offB + kx * BN * BKB + ni * 16 * BKB);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) x[mi] = *(const u32x4*)(Sb + offA[kx] + mi * 16 * BKB);
+            for (int mi = 0; mi < MI; ++mi) if (!((BAND_ABL & 4) && kx > 0)) x[mi] = *(const u32x4*)(Sb + offA[kx] + mi * 16 * BKB);
         };
         auto mm = [&](u32x4 (&w)[NI], u32x4 (&x)[MI]) {
 #pragma unroll
@@ -653,8 +726,8 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-            if (t < 2) rd(t + 1, wf[(t + 1) & 1], xf[(t + 1) & 1]);
-            mm(wf[t & 1], xf[t & 1]);
+            if (t < 2) rd(t + 1, wf[(t + 1) & 1], xf[(BAND_ABL & 4) ? 0 : ((t + 1) & 1)]);
+            mm(wf[t & 1], xf[(BAND_ABL & 4) ? 0 : (t & 1)]);
 #pragma unroll
             for (int sg = 0; sg < SG; ++sg) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
@@ -712,7 +785,7 @@ __global__ __launch_bounds__(512) void conv3x3_band_kernel(const ConvArgs a) {
             for (int ni = 0; ni < NI; ni += 2) {
                 const f32x4 v0 = fin(ni), v1 = fin(ni + 1);
                 u32x4 o = pair_exchange<T>(v0, v1);                                // all lanes
-                if (ok && cb + ni * 16 < a.cout_valid) {
+                if (ok && cb + ni * 16 < a.cout_valid && !((BAND_ABL & 16) && o[0] != 0x12345678u)) {
                     if (epi & DBX_EPI_GATE) o = gate_packed16(o, *(const u32x4*)(grow - g4 * 4 + pair_cout_off(g4, ni)));
                     *(u32x4*)(ypix + pair_cout_off(g4, ni)) = o;
                 }

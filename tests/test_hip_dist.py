@@ -1,6 +1,6 @@
-"""GPU data-parallel equivalence: two ranks (gloo transport, both on cuda:0 -- RCCL needs one device per rank, the
-reducer/step logic is backend-agnostic) each train on half of a batch; parameters after the step must equal the
-single-process step on the concatenated batch (sum-loss => all-reduce SUM without division; global
+"""GPU data-parallel equivalence: WORLD ranks (2 and 8 = configs[3]'s world size; gloo transport, all on cuda:0 -- RCCL needs one
+device per rank, the reducer/step logic is backend-agnostic) each train on their slice of a batch; parameters after the step must
+equal the single-process step on the concatenated batch, and every rank must hold the same parameters (sum-loss => all-reduce SUM without division; global
 positive count => identical mining constants)."""
 import os
 import socket
@@ -12,10 +12,10 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
-KIND, N_PER, WORLD, LR = 'DenseBoxLMLOC', 2, 2, 1e-8
+KIND, N_PER, LR = 'DenseBoxLMLOC', 2, 1e-8
 
 
-def _data():
+def _data(WORLD):
     from densebox_amd import synth, labels as LB
     N = N_PER * WORLD
     x, bbox, vert, lab = synth.synth_batch(N, seed=31, neg_frac=0.3)
@@ -47,14 +47,22 @@ def _rank_main(rank, world, port, out_path):
     try:
         from densebox_amd.dist import DataParallel
         from densebox_amd.optim import SGD
-        x, bbox, vert, lab, rn, lrn = _data()
+        x, bbox, vert, lab, rn, lrn = _data(world)
         net = _make_net()
         dp = DataParallel(net, SGD(net.parameters(), lr=LR), bucket_bytes=4 << 20)
+        from densebox_amd import labels as LB
+        mine = slice(rank * N_PER, (rank + 1) * N_PER)
+        assert dp.global_positive_num(bbox[mine], lab[mine]) == int(LB.positive_count(bbox, lab).sum())    # the int64 all-reduce at this world size
         sl = slice(rank * N_PER, (rank + 1) * N_PER)
         loss = dp.step(x[sl].cuda(), bbox[sl], vert[sl], lab[sl], rand_neg_indices=rn[sl], lm_rand_neg_indices=lrn[:, sl])
         tot = loss.detach().double().cpu().clone()
         dist.all_reduce(tot)
         torch.cuda.synchronize()
+        # every rank holds the same parameters after the step (bitwise: same all-reduced gradient, same update)
+        sums = torch.stack([p.detach().double().sum() for p in net.parameters()]).cpu()
+        gathered = [torch.zeros_like(sums) for _ in range(world)]
+        dist.all_gather(gathered, sums)
+        assert all(torch.equal(g, gathered[0]) for g in gathered), 'ranks diverged after one step'
         if rank == 0:
             torch.save({'loss': float(tot), 'params': {k: p.detach().cpu() for k, p in net.named_parameters()},
                         'grads': {k: p.grad.detach().cpu() for k, p in net.named_parameters() if p.grad is not None}}, out_path)
@@ -62,14 +70,15 @@ def _rank_main(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process(tmp_path):
+@pytest.mark.parametrize('WORLD', [2, 8])
+def test_ranks_equal_one_process(tmp_path, WORLD):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / 'dp.pt')
     mp.spawn(_rank_main, args=(WORLD, port, out), nprocs=WORLD, join=True)
     got = torch.load(out)
     # single process, concatenated batch
     from densebox_amd.optim import SGD
-    x, bbox, vert, lab, rn, lrn = _data()
+    x, bbox, vert, lab, rn, lrn = _data(WORLD)
     net = _make_net()
     opt = SGD(net.parameters(), lr=LR)
     outs = net(x.cuda())
