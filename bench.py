@@ -273,6 +273,11 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    if world > torch.cuda.device_count():
+        # several ranks share a GPU (DBX_DIST_BACKEND=gloo, functional runs of the N > 1 path on a 1-GPU box): create the device
+        # contexts one after the other -- eight processes initialising on one (virtual) device at the same instant faulted once in
+        # the first allocation's fill kernel
+        time.sleep(0.3 * rank)
     local = local % torch.cuda.device_count()          # (several ranks may share a GPU under DBX_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
