@@ -61,6 +61,9 @@ SIGNATURES = {
     'dbx_conv_forward': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _VP, _I32, _VP]),
     'dbx_conv_plan': (C.c_int, [_PC, _PV, _PV, C.POINTER(ConvPlan)]),
     'dbx_conv_forward_split': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _PV, _PV, _PV, _I32, _I32, _VP]),
+    'dbx_heads_forward_fusable': (C.c_int, [_PC, _PV, _PV, C.POINTER(C.c_int32), _I32]),
+    'dbx_heads_forward_fused_scratch_bytes': (_I64, [_I32, _I64]),
+    'dbx_heads_forward_fused': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _VP, _VP, C.POINTER(C.c_int32), _I32, _VP, _VP, _VP]),
     'dbx_dp_unique_id': (C.c_int, [_VP]),
     'dbx_dp_init': (C.c_int, [_VP, _I32, _I32, C.POINTER(C.c_void_p)]),
     'dbx_dp_allreduce_sum_f32': (C.c_int, [_VP, _VP, _I64, _VP]),

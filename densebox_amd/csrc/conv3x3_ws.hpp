@@ -98,6 +98,13 @@ struct WsArgs {
 
 // EPIK: 0 = the epilogue reads its kind from the arguments at run time; 1 = fixed to BIAS + hash dropout on a single destination
 // (the heads' forward GEMM): the flag tests fold away and with them the ReLU / gate / second-destination code.
+// EPIK 2 = EPIK 1 + the heads' SECOND 1x1 convs (DenseBox.py:158-162: Conv1x1(768 -> 512) -> Dropout -> Conv1x1(512 -> k), k <= 8) on
+// the tile while it is in registers: the 16-byte store chunk of a lane (eight consecutive hidden channels of one pixel, rounded and
+// dropped -- exactly what lands in the hidden map) IS the B operand of a v_mfma_f32_32x32x16 whose A operand is the [k rows][16
+// channels] slice of that head's second weight (fragment order, a.w2f); four MFMAs per pixel fragment leave a wave's partial sums over
+// its 64 channels in four accumulator registers per lane, the four waves are summed through the dead band buffer in a fixed order,
+// and the workgroup stores a.part[cout tile][pixel][8] (fp32).  dbx_heads_forward_fused adds a head's two tiles and the bias:
+// the 944 MB hidden map is not read back by a second GEMM (conv_igemm_dma<256,64>: 219 us of the step at batch 64).
 template <typename T, int WM, int KS, int EPIK = 0>
 __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const WsArgs t) {
     using namespace ws;
@@ -322,7 +329,8 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
             // consecutive couts; the four stores of a pixel fragment complete one 128-byte line per pixel.
             // split destination (1x1 only: the data gradient of the fusion concat): cout tiles at or past split_c go to y2 / gate2
             const bool second = EPIK == 0 && a.split_c > 0 && cur.n0 >= a.split_c;
-            const int epi = EPIK == 1 ? (DBX_EPI_BIAS | DBX_EPI_DROPHASH) : (second ? a.epi2 : a.epi);
+            constexpr bool FIX = EPIK >= 1;                            // fixed epilogue: bias + hash dropout
+            const int epi = FIX ? (DBX_EPI_BIAS | DBX_EPI_DROPHASH) : (second ? a.epi2 : a.epi);
             char* const ybase = second ? a.y2 : a.y;
             const char* const gbase = second ? a.gate2 : a.gate;
             const int y_hp = second ? a.y2_hp : a.y_hp, y_wp = second ? a.y2_wp : a.y_wp, y_ld = second ? a.y2_ld : a.y_ld, y_pad = second ? a.y2_pad : a.y_pad;
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    bias[ni][j] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cw + ni * 32 + 8 * j + 4 * h) * (EPIK == 1 ? 2.f : 1.f) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    bias[ni][j] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cw + ni * 32 + 8 * j + 4 * h) * (FIX ? 2.f : 1.f) : (f32x4){0.f, 0.f, 0.f, 0.f};
             int qq = cur.q0 + wm * NF * 32 + l31;
             int n = qq / t.hwp;
             const int rem = qq - n * t.hwp;
@@ -370,6 +378,19 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
 #pragma unroll
                 for (int d = 0; d < PD && d < NF; ++d) gate_fetch(gring[d]);
             }
+            // EPIK 2: this wave's four [32 rows][16 channels] slices of the second weight (block = hidden channel / 16; the image
+            // is dbx_pack_weight mode 4 with 256 rows: eight 1-KiB row blocks per channel block, the first holds rows 0..31)
+            u32x4 w2f[2][2];
+            char* const red = smem + (buf ^ 1) * ABUF;                  // the band buffer the tile has finished with (seam barrier passed)
+            unsigned st_pix[2] = {0u, 0u};
+            bool st_ok[2] = {false, false};
+            if constexpr (EPIK == 2) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp)
+                        w2f[ni][jp] = *(const u32x4*)(a.w2f + (size_t)((cw + ni * 32 + jp * 16) >> 4) * 8192 + lane * 16);
+            }
 #pragma unroll
             for (int mi = 0; mi < NF; ++mi) {
                 const bool ok = qq < t.qtot && fx >= t.xpad && fx < wp - t.xpad;
@@ -377,10 +398,26 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                 T* ypix = (T*)ybase + (size_t)((n * y_hp + oy + y_pad) * y_wp + (ox + y_pad)) * (size_t)y_ld + cy + 8 * h;
                 u32x4 (&gt)[2][2] = gring[mi % PD];
                 const unsigned mpix = (unsigned)((n * H + oy) * Wo + ox);   // output pixel index (dropout counter)
+                f32x16 acc2;
+                if constexpr (EPIK == 2) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+                    if (mi == wn) { st_pix[0] = mpix; st_ok[0] = ok; }      // (wave-uniform tests: the fragments this wave reduces below)
+                    if (mi == wn + 4) { st_pix[1] = mpix; st_ok[1] = ok; }
+                }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     unsigned h32 = 0;                                    // EPIK 1: one hash for this wave's 32 couts of the pixel
-                    if constexpr (EPIK == 1) h32 = dbx_drop_hash32(a.drop_seed, mpix, (unsigned)(cw + ni * 32) >> 5);
+                    // (shifted by this lane half's 4 h once: the per-element fields are then immediate bit positions 8 j + i -- with the
+                    // shift amounts 8 j + 4 h kept as four lane invariants the compiler spilled them, and every scratch reload waits
+                    // vmcnt(0), i.e. for all the output stores in flight)
+                    // The select goes through an SGPR-pair lane mask (inline asm): a lane-dependent shift amount 4 h is one more VGPR invariant, and it
+                    // was the one the allocator spilled next.
+                    if constexpr (FIX) {
+                        const unsigned hraw = dbx_drop_hash32(a.drop_seed, mpix, (unsigned)(cw + ni * 32) >> 5);
+                        const unsigned long long upper = 0xffffffff00000000ull;        // lanes 32..63 (h = 1)
+                        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(h32) : "v"(hraw), "v"(hraw >> 4), "s"(upper));
+                    }
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) {
                         u32x2 pk[2];
@@ -388,7 +425,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                         for (int jj = 0; jj < 2; ++jj) {
                             const int j = 2 * jp + jj;
                             float v[4];
-                            if constexpr (EPIK == 1) {
+                            if constexpr (FIX) {
                                 // 2 (acc + bias) as two v_pk_fma_f32 (bias pre-doubled); a dropped element is cleared by ANDing
                                 // with the sign-extended one-bit field of the hash (v_bfe_i32 + v_and_b32)
                                 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -396,12 +433,12 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                                 const f32x2 lo = (f32x2){acc[ni][mi][4 * j], acc[ni][mi][4 * j + 1]} * two + (f32x2){bias[ni][j][0], bias[ni][j][1]};
                                 const f32x2 hi = (f32x2){acc[ni][mi][4 * j + 2], acc[ni][mi][4 * j + 3]} * two + (f32x2){bias[ni][j][2], bias[ni][j][3]};
                                 v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
-                                const int kb = (int)(h32 >> (8 * j + 4 * h));      // channels 8 j + 4 h + i of the 32-block
+                                // keep bit of channel 8 j + 4 h + i of the 32-block = bit 8 j + i of the pre-shifted hash
                                 // (inline asm: the compiler rewrites the builtin into v_cmp + v_cndmask, twice the work)
 #pragma unroll
                                 for (int i = 0; i < 4; ++i) {
                                     int msk;
-                                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(msk) : "v"(kb), "n"(i));
+                                    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(msk) : "v"(h32), "n"(8 * j + i));
                                     v[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, v[i]) & msk);
                                 }
                                 T p1[4] = {from_f32<T>(v[0]), from_f32<T>(v[1]), from_f32<T>(v[2]), from_f32<T>(v[3])};
@@ -426,6 +463,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                         const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
                         const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
                         u32x4 o = (u32x4){r0[0], r1[0], r0[1], r1[1]};
+                        if constexpr (EPIK == 2) Mma32<T>::run(w2f[ni][jp], o, acc2);
                         if (ok && !(WS_DBG(t) & 2)) {
                             if (epi & DBX_EPI_GATE) o = gate_packed16(o, gt[ni][jp]);
                             *(u32x4*)(ypix + ni * 32 + 16 * jp) = o;
@@ -433,6 +471,8 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                     }
                 }
                 if (EPIK == 0 && (epi & DBX_EPI_GATE) && mi + PD < NF) gate_fetch(gring[mi % PD]);
+                if constexpr (EPIK == 2)         // rows 0..3 (lower half) / 4..7 (upper half) of pixel l31: this wave's partial over its 64 channels
+                    *(f32x4*)(red + ((wn * 8 + mi) * 64 + lane) * 16) = (f32x4){acc2[0], acc2[1], acc2[2], acc2[3]};
                 __builtin_amdgcn_sched_barrier(0);                      // one fragment at a time: bounds the live accumulator copies
                 // advance 32 q': at most one row wrap (Wp >= 32) or a division
                 qq += 32;
@@ -443,6 +483,21 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                     n = qq / t.hwp;
                     const int rr = qq - n * t.hwp;
                     oy = rr / wp; fx = rr - oy * wp;
+                }
+            }
+            if constexpr (EPIK == 2) {
+                // the four waves' partials, summed in wave order; wave w finishes fragments w and w + 4 (its own lanes' pixels)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int mi = wn + 4 * k;
+                    if (mi < NF) {
+                        f32x4 s = *(const f32x4*)(red + ((0 * 8 + mi) * 64 + lane) * 16);
+#pragma unroll
+                        for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + ((w * 8 + mi) * 64 + lane) * 16);
+                        if (st_ok[k]) *(f32x4*)(a.part + ((size_t)(cur.n0 >> 8) * a.M + st_pix[k]) * 8 + 4 * h) = s;
+                    }
                 }
             }
         };

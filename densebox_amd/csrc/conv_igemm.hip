@@ -46,6 +46,9 @@ struct ConvArgs {
     int split_c, epi2, cout_valid2;
     int rowskip;                    // band kernels: tiles over the frame WITHOUT its top / bottom halo rows (q' = (n H + y) Wp + fx)
     unsigned char* pool_idx;        // fused pooling (EPI2_POOL): arg-max nibbles of the pooled map (dbx_maxpool2x2_idx layout), or null
+    // fused stage-2 head convs (ws kernel, EPIK 2: dbx_heads_forward_fused): fragment-order 512 nh -> k weights and the fp32 partial
+    // sums [cout tile][output pixel][8] one workgroup tile contributes to its head's <= 8 outputs
+    const char* w2f; float* part;
 };
 
 // XOR mask (in 16-byte chunks) of a tile row, applied on the LDS-DMA source side and on the fragment reads.
@@ -1478,7 +1481,7 @@ template <typename T>
 static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void* w, const float* bias,
                           const dbx_view* y, const dbx_view* gate, const uint8_t* dropmask, int dm_ld, hipStream_t s,
                           const dbx_view* y2 = nullptr, const dbx_view* gate2 = nullptr, int split_c = 0, int epi2 = 0,
-                          dbx_conv_plan_t* plan = nullptr, void* pool_idx = nullptr) {
+                          dbx_conv_plan_t* plan = nullptr, void* pool_idx = nullptr, const void* w2_frag = nullptr, float* part = nullptr) {
     constexpr int ES = sizeof(T);
     // One selection path for launching and for dbx_conv_plan(): with `plan` set, the chosen kernel is reported instead of launched.
     static const char* const tname = sizeof(T) == 4 ? "f32" : (DType<T>::id == DBX_F16 ? "f16" : "bf16");
@@ -1540,6 +1543,7 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.y2 = nullptr; a.gate2 = nullptr; a.split_c = 0; a.epi2 = 0; a.cout_valid2 = 0;
     a.y2_hp = a.y2_wp = a.y2_ld = a.y2_pad = a.g2_hp = a.g2_wp = a.g2_ld = a.g2_pad = 0;
     a.pool_idx = (unsigned char*)pool_idx;
+    a.w2f = (const char*)w2_frag; a.part = part;
     a.rowskip = 0;
     if (y2 && (epi2 & EPI2_POOL)) {
         // pooled second destination: the 64 -> 64 halo-tile kernel only (dbx_conv_pool_fusable)
@@ -1613,8 +1617,11 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
                              (nogate && wm == 1 && ((d->cin_pad >= 512 && d->cout_pad >= 512) || (d->cin_pad == 256 && d->cout_pad == 256)));
         if (ws_ok && (wfrag || (plan && (ws_pref || ws_level() >= 2)))) {
             a.ntile_n = ctot / (256 / wm);
-            if (k1 && !y2 && (a.epi & ~DBX_EPI_ACCUM) == (DBX_EPI_BIAS | DBX_EPI_DROPHASH) && ws_level() != 3)      // heads forward: fixed epilogue
+            if (k1 && !y2 && (a.epi & ~DBX_EPI_ACCUM) == (DBX_EPI_BIAS | DBX_EPI_DROPHASH) && ws_level() != 3) {    // heads forward: fixed epilogue
+                if (a.w2f) DBX_SELECT_WS(256, 256, 1, 1, 2, (launch_conv_ws<T, 1, 1, 2>(a, x->n, x->h, x->pad, s)));       // + the second 1x1 convs
                 DBX_SELECT_WS(256, 256, 1, 1, 1, (launch_conv_ws<T, 1, 1, 1>(a, x->n, x->h, x->pad, s)));
+            }
+            DBX_REQUIRE(!a.w2f, "heads forward fused: needs the fixed bias + hash-dropout epilogue of the 1x1 ws kernel");
             if (k1) DBX_SELECT_WS(256, 256, 1, 1, 0, (launch_conv_ws<T, 1, 1>(a, x->n, x->h, x->pad, s)));
             if (wm == 1) DBX_SELECT_WS(256, 256, 1, 3, 0, (launch_conv_ws<T, 1, 3>(a, x->n, x->h, 1, s)));
             DBX_SELECT_WS(512, 128, 2, 3, 0, (launch_conv_ws<T, 2, 3>(a, x->n, x->h, 1, s)));
@@ -1750,6 +1757,61 @@ extern "C" int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x,
     if (!d || !x || !y || !y2 || !w_packed) { dbx_set_error("conv split: null argument"); return DBX_ERR_ARG; }
     if (d->dtype == DBX_F32) { dbx_set_error("conv split: 16-bit types only"); return DBX_ERR_DTYPE; }
     DBX_DISPATCH_DTYPE(d->dtype, conv_forward_t, d, x, w_packed, bias, y, gate, nullptr, 0, (hipStream_t)stream, y2, gate2, split_c, epilogue2);
+}
+
+// ---- heads forward, both 1x1 convs in one pass over the pixels (conv3x3_ws_kernel<T, 1, 1, 2>, see conv3x3_ws.hpp)
+struct Heads2Fin { int k[4], off[4], nh, ktot; };
+__global__ void heads2_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias2, float* __restrict__ out, int M, int HW,
+                                     const Heads2Fin hf) {
+    // out[n][off_i + m][r] = bias2[off_i + m] + part[2 i][p][m] + part[2 i + 1][p][m]   (a head's two 256-cout tiles, fixed order)
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < M; p += gridDim.x * blockDim.x) {
+        const int n = p / HW, r = p - n * HW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= hf.nh) break;
+            const float* p0 = part + ((size_t)(2 * i) * M + p) * 8;
+            const float* p1 = part + ((size_t)(2 * i + 1) * M + p) * 8;
+            const f32x4 a0 = *(const f32x4*)p0, b0 = *(const f32x4*)p1;
+            f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, b1 = a1;
+            if (hf.k[i] > 4) { a1 = *(const f32x4*)(p0 + 4); b1 = *(const f32x4*)(p1 + 4); }
+            const float s[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                if (m < hf.k[i]) out[((size_t)n * hf.ktot + hf.off[i] + m) * HW + r] = bias2[hf.off[i] + m] + s[m];
+        }
+    }
+}
+static bool heads_fused_shape_ok(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* hid, const int32_t* k, int nh) {
+    if (!d || !x || !hid || !k || nh < 1 || nh > 4) return false;
+    if (d->dtype == DBX_F32 || d->kh != 1 || d->kw != 1 || d->cpad != 0 || d->cout_pad != 512 * nh || hid->c != 512 * nh) return false;
+    if ((d->epilogue & ~DBX_CONV_WFRAG) != (DBX_EPI_BIAS | DBX_EPI_DROPHASH)) return false;
+    for (int i = 0; i < nh; ++i) if (k[i] < 1 || k[i] > 8) return false;
+    dbx_conv_plan_t pl;
+    dbx_conv_desc dd = *d; dd.epilogue &= ~DBX_CONV_WFRAG;
+    if (dbx_conv_plan(&dd, x, hid, &pl) != DBX_OK) return false;
+    return pl.kernel == DBX_K_WS && strstr(pl.name, ",1,1,1>") != nullptr;       // the 1x1 ws kernel with the fixed epilogue takes this problem
+}
+extern "C" int dbx_heads_forward_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* hid, const int32_t* k, int32_t nh) {
+    return heads_fused_shape_ok(d, x, hid, k, nh) ? 1 : 0;
+}
+extern "C" int64_t dbx_heads_forward_fused_scratch_bytes(int32_t nh, int64_t pixels) { return (int64_t)2 * nh * pixels * 8 * 4 + 256; }
+extern "C" int dbx_heads_forward_fused(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,
+                                       const void* w2_frag, const float* bias2, const int32_t* k, int32_t nh, float* out_nchw,
+                                       void* scratch, void* stream) {
+    if (!d || !x || !hid || !w1_frag || !bias1 || !w2_frag || !bias2 || !k || !out_nchw || !scratch) { dbx_set_error("heads forward fused: null argument"); return DBX_ERR_ARG; }
+    DBX_REQUIRE((d->epilogue & DBX_CONV_WFRAG) && heads_fused_shape_ok(d, x, hid, k, nh),
+                "heads forward fused: needs the 16-bit 1x1 768 -> 512 nh GEMM the ws kernel takes (fragment-order weights, bias + hash dropout), nh <= 4 heads of <= 8 outputs");
+    float* part = (float*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
+    int rc;
+    if (d->dtype == DBX_F16) rc = conv_forward_t<_Float16>(d, x, w1_frag, bias1, hid, nullptr, nullptr, 0, (hipStream_t)stream, nullptr, nullptr, 0, 0, nullptr, nullptr, w2_frag, part);
+    else rc = conv_forward_t<__bf16>(d, x, w1_frag, bias1, hid, nullptr, nullptr, 0, (hipStream_t)stream, nullptr, nullptr, 0, 0, nullptr, nullptr, w2_frag, part);
+    if (rc != DBX_OK) return rc;
+    Heads2Fin hf; hf.nh = nh; hf.ktot = 0;
+    for (int i = 0; i < 4; ++i) { hf.k[i] = i < nh ? k[i] : 0; hf.off[i] = hf.ktot; hf.ktot += hf.k[i]; }
+    const int M = hid->n * hid->h * hid->w, HW = hid->h * hid->w;
+    hipLaunchKernelGGL(heads2_finish_kernel, dim3((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048), dim3(256), 0, (hipStream_t)stream, part, bias2, out_nchw, M, HW, hf);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
 }
 
 // conv1_2 data gradient + conv1_1 weight gradient in one launch (conv3x3_c64_kernel<T, false, true>)

@@ -291,6 +291,35 @@ class Engine:
             return out
         return self._packed(('heads2', 0, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
 
+    def _w_heads2_frag(self, dt):
+        """Stage-2 head weights in MFMA-fragment order for the fused heads forward (dbx_heads_forward_fused): one mode-4 image of 256 rows
+        x 512 nh columns, head i's k_i rows at rows 0.. and columns 512 i.. (the kernel only reads the first 32-row block of each 16-channel
+        column block)."""
+        heads = _HEADS[self.kind]
+        ws = [self._param('conv5_2_%s.weight' % s) for s, _ in heads]
+
+        def build(out):
+            for i, w in enumerate(ws):
+                out = self._pack(dt, 4, w, 256, 512 * len(ws), 1, 1, out=out, row_off=0, k_off=512 * i)
+            return out
+        return self._packed(('heads2', 4, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+
+    def _heads_fused(self, P, dt):
+        """Both 1x1 convs of the heads in one kernel (dbx_heads_forward_fused)?  16-bit training plans whose 768 -> 512 nh GEMM runs on the
+        register-streamed-weights kernel with hash dropout; DBX_HEADS_FUSED=0 keeps the two GEMMs (A/B, tests)."""
+        key = ('heads2', 'fused')
+        r = P.frag.get(key)
+        if r is None:
+            heads = _HEADS[self.kind]
+            nh = len(heads)
+            r = False
+            if P.train and dt != _lib.F32 and os.environ.get('DBX_HEADS_FUSED', '1') != '0' and self._frag_heads(P, dt, 'f'):
+                d = ConvDesc(dt, 1, 1, 0, 768, 512 * nh, _lib.EPI_BIAS | _lib.EPI_DROPHASH | _lib.CONV_WFRAG, 0)
+                ks = (C.c_int32 * nh)(*[k for _, k in heads])
+                r = bool(self.L.dbx_heads_forward_fusable(C.byref(d), C.byref(P.B['fusion'].view()), C.byref(P.B['hid'].view()), ks, nh))
+            P.frag[key] = r
+        return r
+
     def _frag_heads(self, P, dt, which):
         """Fragment-order weights for the heads' 768 -> 512 nh GEMM ('f') / its split-destination data gradient ('b')?"""
         key = ('heads1', which)
@@ -326,6 +355,8 @@ class Engine:
             self._w_heads1(dt, frag=self._frag_heads(P, dt, 'f'))
             self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
             self._w_heads2(dt)
+            if self._heads_fused(P, dt):
+                self._w_heads2_frag(dt)
             self._bias(['conv5_2_' + s_ for s_, _ in heads], 64)
         # the refine branch runs from its fp32 parameters (folded 7x7 conv, dbx_refine_backward) unless DBX_REFINE_LINEAR=0 in training
         rf_convs = kind != 'DenseBox' and train and os.environ.get('DBX_REFINE_LINEAR', '1') == '0'
@@ -353,6 +384,7 @@ class Engine:
         params = [p for _, p in self.net.named_parameters()]
         lay = tuple(self._frag(P, dt, st, wh) for st, _, _ in _BACKBONE for wh in ('f', 'b'))   # layouts the kernels of this plan want
         if train:
+            lay += (self._heads_fused(P, dt),)
             lay += (self._frag_heads(P, dt, 'f'),) + ((self._frag_heads(P, dt, 'ba'), self._frag_heads(P, dt, 'bc')) if self._lin_bwd(dt)
                                                       else (self._frag_heads(P, dt, 'b'),))
         sig = (dt, train, tuple((p._version, p.data_ptr()) for p in params), lay)
@@ -638,17 +670,37 @@ class Engine:
                 dm = self._fill_dropout(P, heads)       # injected masks (parity tests)
                 epi |= _lib.EPI_DROPMASK
             hfrag = (epi & _lib.EPI_DROPMASK) == 0 and self._frag_heads(P, dt, 'f')
-            self._conv(dt, B['fusion'].view(), B['hid'].view(), self._w_heads1(dt, frag=hfrag),
-                       self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh), 1, 1, 0, 768, 512 * nh,
-                       epi | (_lib.CONV_WFRAG if hfrag else 0),
-                       dropmask=dm, dm_ld=512 * nh, drop_seed=P.drop_seed if P.drop_hash else 0)
-            # stage 2: the nh Conv1x1(512 -> k) as ONE block-diagonal GEMM 512 nh -> sum(k) over the full hidden rows (4 KiB contiguous
-            # per pixel instead of four strided 1-KiB slices in four launches); the heads' outputs are channel ranges of one tensor
             ktot = sum(k for _, k in heads)
             big = torch.empty((n, ktot, h4, w4), dtype=torch.float32, device=dev)
-            yv = View(C.c_void_p(big.data_ptr()), n, h4, w4, 0, ktot, 0, ktot)
-            self._conv(dt, B['hid'].view(), yv, self._w_heads2(dt), self._bias(['conv5_2_' + s_ for s_, _ in heads], 64), 1, 1, 0,
-                       512 * nh, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW, alg_ci=512)
+            b1 = self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
+            b2 = self._bias(['conv5_2_' + s_ for s_, _ in heads], 64)
+            if hfrag and P.drop_hash and self._heads_fused(P, dt):
+                # both 1x1 convs of every head in one pass: the second (512 -> k) runs on the hidden tile while it is in registers;
+                # the 944 MB hidden map is written for the backward pass but not read back (dbx_heads_forward_fused)
+                need = L.dbx_heads_forward_fused_scratch_bytes(nh, n * h4 * w4)
+                if getattr(self, '_hf_scratch', None) is None or self._hf_scratch.numel() < need:
+                    self._hf_scratch = torch.empty(int(need), dtype=torch.uint8, device=dev)
+                d = ConvDesc(dt, 1, 1, 0, 768, 512 * nh, epi | _lib.CONV_WFRAG, P.drop_seed)
+                prof = self.profile
+                if prof is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                check(L.dbx_heads_forward_fused(C.byref(d), C.byref(B['fusion'].view()), ptr(self._w_heads1(dt, frag=True)), ptr(b1),
+                                                C.byref(B['hid'].view()), ptr(self._w_heads2_frag(dt)), ptr(b2),
+                                                (C.c_int32 * nh)(*[k for _, k in heads]), nh, ptr(big), ptr(self._hf_scratch), s))
+                if prof is not None:
+                    ev1.record()
+                    prof.append({'kernel': 'conv3x3_ws_kernel<%s,1,1,2>' % ('f16', 'bf16', 'f32')[dt],
+                                 'flops': 2.0 * n * h4 * w4 * (768 * 512 * nh + 512 * ktot), 'start': ev0, 'end': ev1})
+            else:
+                self._conv(dt, B['fusion'].view(), B['hid'].view(), self._w_heads1(dt, frag=hfrag), b1, 1, 1, 0, 768, 512 * nh,
+                           epi | (_lib.CONV_WFRAG if hfrag else 0),
+                           dropmask=dm, dm_ld=512 * nh, drop_seed=P.drop_seed if P.drop_hash else 0)
+                # stage 2: the nh Conv1x1(512 -> k) as ONE block-diagonal GEMM 512 nh -> sum(k) over the full hidden rows (4 KiB contiguous
+                # per pixel instead of four strided 1-KiB slices in four launches); the heads' outputs are channel ranges of one tensor
+                yv = View(C.c_void_p(big.data_ptr()), n, h4, w4, 0, ktot, 0, ktot)
+                self._conv(dt, B['hid'].view(), yv, self._w_heads2(dt), b2, 1, 1, 0,
+                           512 * nh, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW, alg_ci=512)
             o = 0
             for stem, k in heads:
                 outs[stem] = big[:, o:o + k].contiguous()

@@ -102,6 +102,21 @@ typedef struct dbx_conv_plan_t {
 } dbx_conv_plan_t;
 int dbx_conv_plan(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y, dbx_conv_plan_t* out);
 
+/* Heads forward, BOTH 1x1 convs of every head in one pass over the pixels (DenseBox.py:158-162 x nh heads; round 4):
+ *   hid = Dropout(Conv1x1(768 -> 512)(x))  for the nh heads side by side (d: 1x1, cin_pad 768, cout_pad 512 nh, epilogue
+ *   DBX_EPI_BIAS | DBX_EPI_DROPHASH | DBX_CONV_WFRAG, w1_frag = dbx_pack_weight mode 4) -- written to `hid` as dbx_conv_forward would,
+ *   out[n][off_i + m][y][x] = bias2[off_i + m] + sum_c W2_i[m][c] hid[n][y][x][512 i + c]   (fp32 NCHW, [N][sum k][H][W]; off_i = k_0 + .. + k_{i-1})
+ * from the tile while it is in registers (the rounded, dropped values that land in `hid`; fp32 accumulation; fixed summation order).
+ * w2_frag: the nh second weights as ONE dbx_pack_weight mode-4 image of 256 rows x (512 nh) columns, head i's k_i rows at rows
+ * 0..k_i-1 (row_off 0) and columns 512 i.. (k_off 512 i).  scratch: dbx_heads_forward_fused_scratch_bytes(nh, N H W).
+ * dbx_heads_forward_fusable() = 1 where the call is available (16-bit types, k_i <= 8, the problems dbx_conv_plan gives to the 1x1
+ * register-streamed-weights kernel); elsewhere run dbx_conv_forward twice. */
+int dbx_heads_forward_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* hid, const int32_t* k, int32_t nh);
+int64_t dbx_heads_forward_fused_scratch_bytes(int32_t nh, int64_t pixels);
+int dbx_heads_forward_fused(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,
+                            const void* w2_frag, const float* bias2, const int32_t* k, int32_t nh, float* out_nchw, void* scratch,
+                            void* stream);
+
 /* 1x1 GEMM (16-bit types) with a split destination: couts [0, split_c) go to y with d->epilogue / gate, couts
  * [split_c, split_c + y2->c) to y2 with epilogue2 (plain, GATE and/or ACCUM) / gate2.  split_c = y->c, a multiple of 256.
  * Used for the data gradient of the fusion concat (torch.cat, DenseBox.py:219): one pass over the 2048-channel hidden

@@ -863,3 +863,58 @@ def test_nchw_to_framed_slots_equals_one_call_per_slot(dtn):
     torch.cuda.synchronize()
     assert float(tb[..., slot:2 * slot].float().abs().sum()) == 0 and float(tb[..., 3 * slot:].float().abs().sum()) == 0
     assert torch.equal(tb[..., :slot], ta[..., :slot]) and torch.equal(tb[..., 2 * slot:3 * slot], ta[..., 2 * slot:3 * slot])
+
+
+@pytest.mark.parametrize('dtn', ['f16', 'bf16'])
+@pytest.mark.parametrize('ks,n,h,w', [([1, 4, 4, 8], 3, 60, 60), ([1, 4], 5, 60, 60), ([1, 4, 4, 8], 2, 57, 83)])
+def test_heads_forward_fused_equals_the_two_gemms(ks, n, h, w, dtn):
+    """dbx_heads_forward_fused (both 1x1 convs of every head in one pass, DenseBox.py:158-162) against the two-call path: the hidden map
+    is bitwise the one dbx_conv_forward writes (same kernel body, same dropout bits), the head outputs equal the second GEMM's to fp32
+    summation order, and both equal torch fp32 on the rounded operands."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    nh, ktot = len(ks), sum(ks)
+    g = torch.Generator(device='cpu').manual_seed(77)
+    x = torch.relu(torch.randn(n, 768, h, w, generator=g)).cuda()
+    w1 = (torch.randn(512 * nh, 768, 1, 1, generator=g) * 0.05).cuda()
+    b1 = torch.randn(512 * nh, generator=g).cuda()
+    w2 = [(torch.randn(k, 512, 1, 1, generator=g) * 0.05).cuda().contiguous() for k in ks]
+    b2 = torch.zeros(64, device='cuda'); b2[:ktot] = torch.randn(ktot, generator=g).cuda()
+    fx, tx, xv = framed(x, 1, tdt)
+    seed = 0x1234ABCD
+    d = ConvDesc(dt, 1, 1, 0, 768, 512 * nh, _lib.EPI_BIAS | _lib.EPI_DROPHASH | _lib.CONV_WFRAG, seed)
+    karr = (C.c_int32 * nh)(*ks)
+    fa, ta, hva = framed(torch.zeros(n, 512 * nh, h, w), 0, tdt)
+    if not L.dbx_heads_forward_fusable(C.byref(d), C.byref(xv), C.byref(hva), karr, nh):
+        pytest.skip('the 1x1 ws kernel does not take this problem')
+    w1f = pack(L, dt, w1, 768, 512 * nh, mode=4)
+    # second weights: fragment image (256 rows, head i at rows 0.., columns 512 i..) and the block-diagonal [64][512 nh] matrix
+    d2f = ConvDesc(dt, 1, 1, 0, 512 * nh, 256, 0)
+    w2f = torch.zeros(L.dbx_conv_packed_elems(C.byref(d2f)) * 2, dtype=torch.uint8, device='cuda')
+    d2 = ConvDesc(dt, 1, 1, 0, 512 * nh, 64, 0)
+    w2b = torch.zeros(L.dbx_conv_packed_elems(C.byref(d2)) * 2, dtype=torch.uint8, device='cuda')
+    r = 0
+    for i, (wt, k) in enumerate(zip(w2, ks)):
+        check(L.dbx_pack_weight(dt, 4, ptr(wt), k, 512, 1, 1, ptr(w2f), 256, 512 * nh, 0, 512 * i, stream_ptr()))
+        check(L.dbx_pack_weight(dt, 0, ptr(wt), k, 512, 1, 1, ptr(w2b), 64, 512 * nh, r, 512 * i, stream_ptr()))
+        r += k
+    out_a = torch.full((n, ktot, h, w), 7.0, device='cuda')
+    sc = torch.empty(L.dbx_heads_forward_fused_scratch_bytes(nh, n * h * w), dtype=torch.uint8, device='cuda')
+    check(L.dbx_heads_forward_fused(C.byref(d), C.byref(xv), ptr(w1f), ptr(b1), C.byref(hva), ptr(w2f), ptr(b2), karr, nh, ptr(out_a), ptr(sc),
+                                    stream_ptr()))
+    fb, tb, hvb = framed(torch.zeros(n, 512 * nh, h, w), 0, tdt)
+    check(L.dbx_conv_forward(C.byref(d), C.byref(xv), ptr(w1f), ptr(b1), C.byref(hvb), None, None, 0, stream_ptr()))
+    out_b = torch.full((n, ktot, h, w), 7.0, device='cuda')
+    yv = View(C.c_void_p(out_b.data_ptr()), n, h, w, 0, ktot, 0, ktot)
+    dd = ConvDesc(dt, 1, 1, 0, 512 * nh, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
+    check(L.dbx_conv_forward(C.byref(dd), C.byref(hvb), ptr(w2b), ptr(b2), C.byref(yv), None, None, 0, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(fa, fb) and float(ta.float().abs().sum()) > 0
+    scale = float(out_b.abs().max())
+    assert float((out_a - out_b).abs().max()) <= 2e-5 * scale, (float((out_a - out_b).abs().max()), scale)
+    hid = tb.permute(0, 3, 1, 2).float()
+    ref = torch.cat([F.conv2d(hid[:, 512 * i:512 * (i + 1)], w2[i].to(tdt).float()) for i in range(nh)], 1) + b2[:ktot].view(1, -1, 1, 1)
+    assert float((out_a - ref).abs().max()) <= 1e-4 * scale
+    # about half of the hidden map is dropped, the rest doubled: the dropout bits are live
+    frac = float((ta == 0).float().mean())
+    assert 0.35 < frac < 0.85, frac
