@@ -293,6 +293,13 @@ def main():
     # synthetic data, resident in HBM before the timed region; every rank draws its own shard of the global batch
     x, bbox, vert, lab = synth.synth_batch(n, seed=100 + rank, neg_frac=0.1)
     x = x.to(dev)
+    if os.environ.get('DBX_BENCH_ZERO') == '1':
+        # power experiment, never a reported number: all-zero images and parameters -- same instruction streams,
+        # (almost) no operand toggling; how much faster the step runs says how far the part is power-managed on real data
+        x.zero_()
+        with torch.no_grad():
+            for p_ in net.parameters():
+                p_.zero_()
     rs = np.random.RandomState(1234 + rank)
     use_lab = lab if kind == 'DenseBoxLMLOC' else None
     half = 0

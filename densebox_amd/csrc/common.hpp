@@ -57,6 +57,8 @@ struct DbxDevOnce {
     void mark(int dev) { done.fetch_or(1ull << (dev & 63), std::memory_order_release); }
 };
 
+namespace pipe { template <int N> struct IC { static constexpr int value = N; }; }   // compile-time indices for generic lambdas
+
 static inline int dbx_esize(int dtype) { return dtype == DBX_F32 ? 4 : 2; }
 
 // ---- device-side dtype helpers ---------------------------------------------------------------

@@ -41,7 +41,6 @@ template <> struct Mma32<__bf16> {
     }
 };
 
-namespace pipe { template <int N> struct IC { static constexpr int value = N; }; }   // compile-time step indices for generic lambdas
 
 
 namespace ws {

@@ -97,6 +97,8 @@ int main(int argc, char** argv) {
         {"dgrad3_1 256->128 @60 gate", 64, 60, 60, 256, 128, DBX_EPI_GATE},
         {"odd 192->256 @33x47 N5", 5, 33, 47, 192, 256, RG},
         {"odd 128->128 @41x29 N7 gate", 7, 41, 29, 128, 128, DBX_EPI_GATE | DBX_EPI_BIAS},
+        {"conv1_2 64->64 @240 N64", 64, 240, 240, 64, 64, RG},
+        {"dgrad1_2 64->64 @240 N64 gate", 64, 240, 240, 64, 64, DBX_EPI_GATE},
     };
     hipStream_t st; CK(hipStreamCreate(&st));
     for (int si = 0; si < (int)(sizeof shapes / sizeof shapes[0]); ++si) {
