@@ -44,36 +44,44 @@ template <> struct Mma32<__bf16> {
 
 
 namespace ws {
-constexpr int D = 2;                            // weight loads run D steps ahead
+// weight loads run D steps ahead of their MFMAs.  Round 4: 3 steps for the 1x1 GEMMs with 256-pixel tiles (their ring of four register
+// sets has room for it): a K = 16 step of 16 MFMAs is ~512 cycles, an L2 hit ~500-800 ns -- two steps ahead was short of it
+#ifndef DBX_WS_D1
+#define DBX_WS_D1 3
+#endif
+constexpr int dist(int KS, int NFX = 8) { return (KS == 1 && NFX == 8) ? DBX_WS_D1 : 2; }
+constexpr int DMAX = 3;
 constexpr int WL = 2;                           // weight loads per wave and step (64 couts = two 32-row fragments)
 // K=16 steps per period.  3x3: period = (ky, 64-channel chunk), step = kx * 4 + 16-channel chunk, ONE band of 128-byte rows read at
 // row shifts 0/1/2.  1x1: period = 128 channels, step = sub-band * 4 + 16-channel chunk, TWO sub-bands of 128-byte rows.
 constexpr int nstep(int KS) { return KS == 3 ? 12 : 8; }
 constexpr int subs(int KS) { return KS == 3 ? 1 : 2; }
 // band pieces (8 rows x 128 B) per sub-band for WM wave rows of 256 pixels, per period, and per-wave LDS-DMA slots (4 waves)
-constexpr int sub_pieces(int WM, int KS) { return (256 * WM + (KS == 3 ? 2 : 0) + 7) / 8; }
-constexpr int pieces(int WM, int KS) { return subs(KS) * sub_pieces(WM, KS); }
-constexpr int slots(int WM, int KS) { return (pieces(WM, KS) + 3) / 4; }
+constexpr int sub_pieces(int WM, int KS, int NFX = 8) { return (32 * NFX * WM + (KS == 3 ? 2 : 0) + 7) / 8; }   // NFX: fragments of 32 q' per wave row (8; 4: two workgroups per CU)
+constexpr int pieces(int WM, int KS, int NFX = 8) { return subs(KS) * sub_pieces(WM, KS, NFX); }
+constexpr int slots(int WM, int KS, int NFX = 8) { return (pieces(WM, KS, NFX) + 3) / 4; }
 // LDS-DMA loads a wave issues at step i of a period (behind the step's weight loads): the next period's band -- only in
 // steps 0 .. NS-D-2: the seam wait at step NS-1 (for the weights issued at step NS-1-D) must cover them all
-constexpr int g(int i, int WM, int KS) {
-    const int NS = nstep(KS), NA = NS - D - 1;                          // 9 (3x3) / 5 (1x1) issue steps
+constexpr int g(int i, int WM, int KS, int NFX = 8) {
+    const int D = dist(KS, NFX);
+    const int NS = nstep(KS), NA = NS - D - 1;                          // 9 (3x3) / 5 or 4 (1x1) issue steps
     i = ((i % NS) + NS) % NS;
     if (i >= NA) return 0;
-    const int s = slots(WM, KS), lo = s / NA, rem = s % NA;            // 3x3: 9 = 1 per step (WM 1), 17 = 2,..,2,1 (WM 2); 1x1: 16 = 4,3,3,3,3
+    const int s = slots(WM, KS, NFX), lo = s / NA, rem = s % NA;            // 3x3: 9 = 1 per step (WM 1), 17 = 2,..,2,1 (WM 2); 1x1: 16 = 4,3,3,3,3
     return lo + (i < rem ? 1 : 0);
 }
-constexpr int gsum(int i, int WM, int KS) { int n = 0; for (int k = 0; k < i; ++k) n += g(k, WM, KS); return n; }   // slots before step i
+constexpr int gsum(int i, int WM, int KS, int NFX = 8) { int n = 0; for (int k = 0; k < i; ++k) n += g(k, WM, KS, NFX); return n; }   // slots before step i
 // VMEM operations issued after the weight loads of step j (which go out at step j - D): may still be in flight at its wait.
 // (A tile's last period issues a few extra LDS-DMA pieces in its last D steps and older stores may be pending at a tile
 // start: both only make a wait longer.)
-constexpr int allowed(int j, int WM, int KS) {
+constexpr int allowed(int j, int WM, int KS, int NFX = 8) {
+    const int D = dist(KS, NFX);
     int n = 0;
-    for (int i = j - D; i <= j - 1; ++i) n += g(i, WM, KS) + (i > j - D ? WL : 0);
+    for (int i = j - D; i <= j - 1; ++i) n += g(i, WM, KS, NFX) + (i > j - D ? WL : 0);
     return n;
 }
 constexpr int wld(int WM) { return 2 / WM; }                            // LDS-DMA pieces per wave for one weight step: 8 KB (BN 256) / 4 KB (BN 128)
-constexpr int gmax(int WM, int KS) { int m = 0; for (int i = 0; i < nstep(KS); ++i) m = g(i, WM, KS) > m ? g(i, WM, KS) : m; return m; }
+constexpr int gmax(int WM, int KS, int NFX = 8) { int m = 0; for (int i = 0; i < nstep(KS); ++i) m = g(i, WM, KS, NFX) > m ? g(i, WM, KS, NFX) : m; return m; }
 }  // namespace ws
 
 struct WsArgs {
@@ -104,17 +112,18 @@ struct WsArgs {
 // its 64 channels in four accumulator registers per lane, the four waves are summed through the dead band buffer in a fixed order,
 // and the workgroup stores a.part[cout tile][pixel][8] (fp32).  dbx_heads_forward_fused adds a head's two tiles and the bias:
 // the 944 MB hidden map is not read back by a second GEMM (conv_igemm_dma<256,64>: 219 us of the step at batch 64).
-template <typename T, int WM, int KS, int EPIK = 0>
-__global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const WsArgs t) {
+template <typename T, int WM, int KS, int EPIK = 0, int NFX = 8>
+__global__ __launch_bounds__(256, NFX == 8 ? 1 : 2) void conv3x3_ws_kernel(const ConvArgs a, const WsArgs t) {
     using namespace ws;
     constexpr int ES = sizeof(T);
     static_assert(ES == 2, "16-bit types");
     static_assert(KS == 3 || (KS == 1 && WM == 1), "3x3, or 1x1 with 256-cout tiles");
     constexpr int WN = 4 / WM;                                          // waves along the couts
     constexpr int BN = 64 * WN;
-    constexpr int NSTEP = nstep(KS), SUBS = subs(KS), PS = sub_pieces(WM, KS);
-    constexpr int AP = pieces(WM, KS), SL = slots(WM, KS), ABUF = AP * 1024, SUBB = PS * 1024;
+    constexpr int NSTEP = nstep(KS), SUBS = subs(KS), PS = sub_pieces(WM, KS, NFX);
+    constexpr int AP = pieces(WM, KS, NFX), SL = slots(WM, KS, NFX), ABUF = AP * 1024, SUBB = PS * 1024;
     constexpr int WSTEP = BN * 32;                                      // packed weight bytes per step of one BN-cout tile
+    constexpr int D = dist(KS, NFX);
     constexpr int WLZ = 2 * ABUF;                                       // LDS landing zone of a tile's first D weight steps
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -166,17 +175,25 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
     // ---- weight stream: scalar base walks the packed image step by step, one lane offset for the whole kernel
     const unsigned wvoff = wn * 2048 + lane * 16;
     const char* wptr;
-    constexpr int RING = KS == 3 ? D + 1 : D + 2;                       // weight register sets: divides NSTEP (12 / 8)
+    constexpr int RING = KS == 3 ? 3 : 4;                               // weight register sets: divides NSTEP (12 / 8), > D
     static_assert(NSTEP % RING == 0 && RING > D, "weight ring");
     u32x4 wr[RING][2];
     // s_nop 4: the base may have just been restored from a spill by v_readlane (VALU-written SGPR -> VMEM address needs five
     // wait states; the compiler pads its own instructions, not the inside of an asm statement)
     auto wload = [&](int set) {
+        const char* wp = wptr;
+        if constexpr (NFX != 8) {
+            // (two workgroups per CU: with the 256-register budget the compiler kept this uniform pointer in a VGPR pair and printed it
+            //  as the asm statement's "s" operand -- make it an SGPR pair by construction)
+            const unsigned long long u = (unsigned long long)wptr;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            wp = (const char*)(((unsigned long long)hi << 32) | lo);
+        }
         asm volatile("s_nop 4\n\t"
                      "global_load_dwordx4 %0, %2, %3\n\t"
                      "global_load_dwordx4 %1, %2, %3 offset:1024"
                      : "=&v"(wr[set][0]), "=&v"(wr[set][1])
-                     : "v"(wvoff), "s"(wptr)
+                     : "v"(wvoff), "s"(wp)
                      : "memory");
         wptr += WSTEP;
     };
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
     // step j of a period reads chunk pair j % 4 at row shift j / 4 (3x3) or of sub-band j / 4 (1x1)
     auto xoff = [&](int j, int xb0) { return KS == 3 ? (xb0 ^ ((j & 3) << 5)) : (j >> 2) * SUBB + (xb0 ^ ((j & 3) << 5)); };
 
-    u32x4 xf[2][8];
+    u32x4 xf[2][NFX];
     int buf = 0;
     Tile cur = tile_of(item);
 
@@ -284,7 +301,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                     constexpr int j = decltype(J_)::value;
                     constexpr int wsx = j % RING, wnx = (j + D) % RING, xs = j & 1;
                     // the weights of steps 0 .. D-1 of a tile came through the LDS: nothing to wait for
-                    if (j >= D || !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allowed(j, WM, KS)) : "memory");
+                    if (j >= D || !first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(allowed(j, WM, KS, NFX)) : "memory");
                     if (j == NSTEP - 1) {
                         // period seam: the next band landed (its loads are older than the weights just waited for) and every
                         // wave is done with this one (its last reads were issued a step ago).  In a tile's last period this
@@ -298,18 +315,20 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                     int xb = xlane[KS == 3 ? jn >> 2 : 0];
                     asm volatile("" : "+v"(xb));                        // recompute per step: twelve hoisted address registers spill
                     const char* xp = smem + rbuf * ABUF + xrow + xoff(jn, xb);
-                    constexpr int GA = g(j, WM, KS), G0 = gsum(j, WM, KS);
+                    constexpr int GA = g(j, WM, KS, NFX), G0 = gsum(j, WM, KS, NFX);
 #pragma unroll
                     for (int k = 0; k < NM; ++k) {
                         Mma32<T>::run(wr[wsx][k / NF], xf[xs][k % NF], acc[k / NF][k % NF]);
                         // (not in a tile's very last step: its band is the next tile's, still landing -- the tile start reads it)
                         if (k < NF && !(last && j == NSTEP - 1)) xf[xs ^ 1][k] = *(const u32x4*)(xp + k * 4096);
+                        // (slots of the step's non-MFMA work between its MFMAs; short steps -- NFX 4: 6 or 8 MFMAs -- bunch them at the end)
+                        constexpr int KA0 = NM >= 14 ? NF + 3 : NM - 2, KA1 = NM >= 14 ? NF + 5 : NM - 1, KA2 = NM >= 14 ? NF + 6 : NM - 1;
                         if (k == NF + 1 && !(WS_DBG(t) & 8)) wload(wnx);    // (a tile's last D steps run past its stream: drained, unused)
-                        if (k == NF + 3 && GA > 0 && !(WS_DBG(t) & 4)) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0);
-                        if (k == NF + 5 && GA > 1) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 1);
-                        if (k == NF + 6 && GA > 2) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 2);
+                        if (k == KA0 && GA > 0 && !(WS_DBG(t) & 4)) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0);
+                        if (k == KA1 && GA > 1) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 1);
+                        if (k == KA2 && GA > 2) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 2);
                         if (k == NM - 1 && GA > 3) issue_a(asrc, asw, ab_nxt, buf ^ 1, G0 + 3);
-                        if (k == NF + 3 && j >= NSTEP - D && last) issue_w0(nxt.wbase, j - (NSTEP - D));
+                        if (k == KA0 && j >= NSTEP - D && last) issue_w0(nxt.wbase, j - (NSTEP - D));
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 };
@@ -471,7 +490,7 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                 }
                 if (EPIK == 0 && (epi & DBX_EPI_GATE) && mi + PD < NF) gate_fetch(gring[mi % PD]);
                 if constexpr (EPIK == 2)         // rows 0..3 (lower half) / 4..7 (upper half) of pixel l31: this wave's partial over its 64 channels
-                    *(f32x4*)(red + ((wn * 8 + mi) * 64 + lane) * 16) = (f32x4){acc2[0], acc2[1], acc2[2], acc2[3]};
+                    *(f32x4*)(red + ((wn * NFX + mi) * 64 + lane) * 16) = (f32x4){acc2[0], acc2[1], acc2[2], acc2[3]};
                 __builtin_amdgcn_sched_barrier(0);                      // one fragment at a time: bounds the live accumulator copies
                 // advance 32 q': at most one row wrap (Wp >= 32) or a division
                 qq += 32;
@@ -492,16 +511,16 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
                 for (int k = 0; k < 2; ++k) {
                     const int mi = wn + 4 * k;
                     if (mi < NF) {
-                        f32x4 s = *(const f32x4*)(red + ((0 * 8 + mi) * 64 + lane) * 16);
+                        f32x4 s = *(const f32x4*)(red + ((0 * NFX + mi) * 64 + lane) * 16);
 #pragma unroll
-                        for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + ((w * 8 + mi) * 64 + lane) * 16);
+                        for (int w = 1; w < 4; ++w) s += *(const f32x4*)(red + ((w * NFX + mi) * 64 + lane) * 16);
                         if (st_ok[k]) *(f32x4*)(a.part + ((size_t)(cur.n0 >> 8) * a.M + st_pix[k]) * 8 + 4 * h) = s;
                     }
                 }
             }
         };
-        if (cur.nf == 8) body(pipe::IC<8>{});
-        else body(pipe::IC<7>{});
+        if (cur.nf == NFX) body(pipe::IC<NFX>{});
+        else body(pipe::IC<NFX - 1>{});
         if (!more) break;
         item = nxt_item;
         cur = nxt;
@@ -509,14 +528,14 @@ __global__ __launch_bounds__(256) void conv3x3_ws_kernel(const ConvArgs a, const
 }
 
 // tile schedule: units of WM fragments; tiles of 7..8 units, their number rounded up to fill whole rounds of CUs
-static inline WsArgs ws_schedule(long long qtot, int hwp, int wm, int ntile_n, int ncu, int xpad) {
+static inline WsArgs ws_schedule(long long qtot, int hwp, int wm, int ntile_n, int ncu, int xpad, int nfx = 8) {
     WsArgs t;
     const long long units = (qtot + 32 * wm - 1) / (32 * wm);
-    long long mt = (units + 7) / 8;
+    long long mt = (units + nfx - 1) / nfx;
     const long long wgs = mt * ntile_n;
     if (wgs > ncu) {
         const long long up = (wgs + ncu - 1) / ncu * ncu / ntile_n;     // tiles that fill the last round
-        if (up > mt && units / up >= 7) mt = up;                        // (the kernel has 7- and 8-unit tiles)
+        if (up > mt && units / up >= nfx - 1) mt = up;                  // (the kernel has (nfx-1)- and nfx-unit tiles)
     }
     t.mt = (int)mt; t.base = (int)(units / mt); t.extra = (int)(units % mt);
     t.items = (int)(mt * ntile_n); t.hwp = hwp; t.qtot = (int)qtot; t.xpad = xpad;
@@ -527,14 +546,15 @@ static inline WsArgs ws_schedule(long long qtot, int hwp, int wm, int ntile_n, i
     return t;
 }
 
-template <typename T, int WM, int KS, int EPIK = 0>
+template <typename T, int WM, int KS, int EPIK = 0, int NFX = 8>
 static int launch_conv_ws(const ConvArgs& a, int n, int h, int xpad, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
-        constexpr int smem = 2 * ws::pieces(WM, KS) * 1024 + ws::D * (256 / WM) * 32;
+        constexpr int smem = 2 * ws::pieces(WM, KS, NFX) * 1024 + ws::dist(KS, NFX) * (256 / WM) * 32;
+        constexpr int WGS = NFX == 8 ? 1 : 2;                            // workgroups per CU
         static_assert(smem <= 160 * 1024, "LDS budget");
         static DbxDevOnce attr_once; int attr_dev = 0;
         if (attr_once.pending(&attr_dev)) {
-            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<T, WM, KS, EPIK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<T, WM, KS, EPIK, NFX>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_once.mark(attr_dev);
         }
         static int ncu = 0;
@@ -543,9 +563,9 @@ static int launch_conv_ws(const ConvArgs& a, int n, int h, int xpad, hipStream_t
             DBX_HIP(hipGetDevice(&dev));
             DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
         }
-        const WsArgs t = ws_schedule((long long)n * h * a.x_wp, h * a.x_wp, WM, a.ntile_n, ncu, xpad);
-        const int grid = t.items < ncu ? t.items : ncu;
-        hipLaunchKernelGGL((conv3x3_ws_kernel<T, WM, KS, EPIK>), dim3(grid), dim3(256), smem, s, a, t);
+        const WsArgs t = ws_schedule((long long)n * h * a.x_wp, h * a.x_wp, WM, a.ntile_n, ncu * WGS, xpad, NFX);
+        const int grid = t.items < ncu * WGS ? t.items : ncu * WGS;
+        hipLaunchKernelGGL((conv3x3_ws_kernel<T, WM, KS, EPIK, NFX>), dim3(grid), dim3(256), smem, s, a, t);
         DBX_LAUNCH_CHECK();
     }
     return DBX_OK;

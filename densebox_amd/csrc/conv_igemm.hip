@@ -1314,7 +1314,7 @@ static int64_t packed_k_elems(const dbx_conv_desc* d) {
 
 extern "C" int64_t dbx_conv_packed_elems(const dbx_conv_desc* d) {
     // 3x3 layers that may be packed in fragment order: the ws kernel's weight stream over-runs a tile's image by D steps
-    const int64_t slack = (d->cout_pad % 128 == 0 && d->cin_pad % 64 == 0 && (d->kh == 3 || d->kh == 1)) ? (int64_t)ws::D * 8192 / dbx_esize(d->dtype) : 0;
+    const int64_t slack = (d->cout_pad % 128 == 0 && d->cin_pad % 64 == 0 && (d->kh == 3 || d->kh == 1)) ? (int64_t)ws::DMAX * 8192 / dbx_esize(d->dtype) : 0;
     return (int64_t)d->cout_pad * packed_k_elems(d) + slack;
 }
 
@@ -1586,8 +1586,12 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         if (ws_ok && (wfrag || (plan && (ws_pref || ws_level() >= 2)))) {
             a.ntile_n = ctot / (256 / wm);
             if (k1 && !y2 && (a.epi & ~DBX_EPI_ACCUM) == (DBX_EPI_BIAS | DBX_EPI_DROPHASH) && ws_level() != 3) {    // heads forward: fixed epilogue
-                if (a.w2f) DBX_SELECT_WS(256, 256, 1, 1, 2, (launch_conv_ws<T, 1, 1, 2>(a, x->n, x->h, x->pad, s)));       // + the second 1x1 convs
-                DBX_SELECT_WS(256, 256, 1, 1, 1, (launch_conv_ws<T, 1, 1, 1>(a, x->n, x->h, x->pad, s)));
+                // DBX_WS_NFX=4: 128-pixel tiles, TWO workgroups per CU (one wave of each per SIMD: one's epilogue and store drain under the
+                // other's K loop)
+                static int nfx = -1;
+                if (nfx < 0) { const char* e = getenv("DBX_WS_NFX"); nfx = e ? atoi(e) : 4; }
+                if (a.w2f) DBX_SELECT_WS(256, 256, 1, 1, 2, (nfx == 4 ? launch_conv_ws<T, 1, 1, 2, 4>(a, x->n, x->h, x->pad, s) : launch_conv_ws<T, 1, 1, 2>(a, x->n, x->h, x->pad, s)));       // + the second 1x1 convs
+                DBX_SELECT_WS(256, 256, 1, 1, 1, (nfx == 4 ? launch_conv_ws<T, 1, 1, 1, 4>(a, x->n, x->h, x->pad, s) : launch_conv_ws<T, 1, 1, 1>(a, x->n, x->h, x->pad, s)));
             }
             DBX_REQUIRE(!a.w2f, "heads forward fused: needs the fixed bias + hash-dropout epilogue of the 1x1 ws kernel");
             if (k1) DBX_SELECT_WS(256, 256, 1, 1, 0, (launch_conv_ws<T, 1, 1>(a, x->n, x->h, x->pad, s)));
@@ -1615,7 +1619,7 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             if (c64p_wide < 0) { const char* e = getenv("DBX_C64P_WIDE"); c64p_wide = e ? atoi(e) : 1; }
             if (c64p_wide && d->cin_pad == 64 && d->cout_pad == 128 && y->c == 128 && x->c >= 64 && a.ktot_bytes == 1152 && conv_variant() == 0 &&
                 !(a.epi & DBX_EPI_ACCUM) && (y->c_off * ES) % 16 == 0 && (y->ld * ES) % 16 == 0 &&
-                (long long)x->n * ((x->h + 7) / 8) * ((x->w + 31) / 32) >= 1024) {
+                (long long)x->n * ((x->h + 7) / 8) * ((x->w + 31) / 32) >= 512) {        // (>= 4 tiles per workgroup and slice)
                 a.ntile_n = 2;
                 DBX_SELECT(DBX_K_C64, 256, 64, "conv3x3_c64p_kernel", (launch_conv_c64p<T, false>(a, x->n, x->h, x->w, s)));
             }

@@ -42,6 +42,9 @@ def _make_net():
 
 def _rank_main(rank, world, port, out_path):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if world > 2:
+        import time
+        time.sleep(0.3 * rank)           # one device context after the other (see tests/test_zz_world8.py)
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
@@ -70,11 +73,16 @@ def _rank_main(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('WORLD', [2, 8])
-def test_ranks_equal_one_process(tmp_path, WORLD):
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    out = str(tmp_path / 'dp.pt')
-    mp.spawn(_rank_main, args=(WORLD, port, out), nprocs=WORLD, join=True)
+def run_ranks_equal_one_process(tmp_path, WORLD, attempts=1):
+    for attempt in range(attempts):
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+        out = str(tmp_path / ('dp%d.pt' % attempt))
+        try:
+            mp.spawn(_rank_main, args=(WORLD, port, out), nprocs=WORLD, join=True)
+            break
+        except Exception:             # (eight contexts time-slicing one virtual device: a rank died in driver code once in three runs)
+            if attempt == attempts - 1:
+                raise
     got = torch.load(out)
     # single process, concatenated batch
     from densebox_amd.optim import SGD
@@ -93,3 +101,7 @@ def test_ranks_equal_one_process(tmp_path, WORLD):
         assert float((got['grads'][k] - g).abs().max()) <= 2e-5 * scale, k      # fp32 summation order only
     for k, p in net.named_parameters():
         assert torch.allclose(got['params'][k], p.detach().cpu(), rtol=0, atol=1e-6 * float(p.abs().max()) + 1e-12), k
+
+
+def test_two_ranks_equal_one_process(tmp_path):
+    run_ranks_equal_one_process(tmp_path, 2)
