@@ -678,10 +678,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3x3_band_kernel(const ConvAr
     for (int d = 0; d < DEPTH; ++d)
         if (d < nk) issue();
     int stage = 0;
+#ifdef BAND_TS                        // lab builds (tools/band_lab.hip): shader-clock stamps around the stage barrier, a.part = [wg < 64][wave][stage < 64][3] u64
+    unsigned long long* const ts = (unsigned long long*)a.part + ((size_t)(blockIdx.x & 63) * NW + wave) * 64 * 3;
+#endif
     for (int ks = 0; ks < nk; ++ks) {
         const int younger = nk - 1 - ks;
+#ifdef BAND_TS
+        const unsigned long long t_a = __builtin_readcyclecounter();
+#endif
         wait_young(younger < DEPTH - 1 ? younger : DEPTH - 1);
+#ifdef BAND_TS
+        const unsigned long long t_w = __builtin_readcyclecounter();
+#endif
         __builtin_amdgcn_s_barrier();
+#ifdef BAND_TS
+        const unsigned long long t_b = __builtin_readcyclecounter();
+        if (lane == 0 && blockIdx.x < 64 && ks < 64) { ts[ks * 3] = t_a; ts[ks * 3 + 1] = t_w; ts[ks * 3 + 2] = t_b; }
+#endif
         if (ks + DEPTH < nk) issue();
         const char* Sb = smem + stage * STAGE;
         // software pipeline over the three taps: the fragments of tap kx+1 are read while tap kx's MFMAs run
@@ -1573,13 +1586,13 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         // Which eligible problems the plan PREFERS on it (same-box A/B inside the training step, profiles/r02_ws_vs_band.txt): the kernel's
         // fixed cost per tile (prologue, one-wave-per-SIMD epilogue with nothing to overlap it) is amortised over the K loop: it wins on
         // the un-gated 512 -> 512 and 256 -> 256 layers, on 128-cout layers with >= 256 input channels, and on the 1x1 heads; the LDS band
-        // kernels keep the rest.  Round 3 (gate chunks prefetched four fragments ahead in its epilogue): the GATED 512 -> 512 / 256 -> 256
-        // data gradients run 4-7 % faster on it in isolation (conv4: 224 vs 234-242 us, conv3: 246-256 vs 260-272) -- and the whole
-        // training step 1.2 % SLOWER (10.51 vs 10.38 ms, three alternating same-box pairs): every other MFMA kernel of the step slows
-        // by 2-3 % when these five run hotter (the part is power-managed: 1180 W, sclk 2.11 GHz average over the step), so the plan keeps
-        // the band kernel there; DBX_WS_GATED=1 prefers ws on them.  A caller may still force it with DBX_CONV_WFRAG.
+        // kernels keep the rest.  The GATED 512 -> 512 / 256 -> 256 data gradients (gate chunks prefetched four fragments ahead in its
+        // epilogue): round 3 kept them on the band kernel on the strength of three same-box pairs (step 1.2 % slower with ws, read as power
+        // coupling).  Round 4 repeated it with five alternating pairs, per-kernel durations AND clocks for both arms
+        // (profiles/r04_power_ab.txt): the step is 0.2 % FASTER with ws on them (9.219 vs 9.236 ms; kernel time of the two families
+        // -48 us per step), no other kernel's clock moves -- the round-3 reading is retired and ws takes them.  DBX_WS_GATED=0: band.
         static int ws_gated = -1;
-        if (ws_gated < 0) { const char* e = getenv("DBX_WS_GATED"); ws_gated = e ? atoi(e) : 0; }
+        if (ws_gated < 0) { const char* e = getenv("DBX_WS_GATED"); ws_gated = e ? atoi(e) : 1; }
         const bool nogate = !(d->epilogue & DBX_EPI_GATE) || ws_gated != 0;
         const bool ws_pref = k1 || (wm == 2 && d->cin_pad >= 256) ||
                              (nogate && wm == 1 && ((d->cin_pad >= 512 && d->cout_pad >= 512) || (d->cin_pad == 256 && d->cout_pad == 256)));

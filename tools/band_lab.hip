@@ -142,7 +142,29 @@ int main(int argc, char** argv) {
             const bool frag = v == 8 || v == 7 || (v >= 70 && v < 80);
             const __bf16* wuse = frag ? wtl : wpk;
             d.epilogue = S.epi | (v == 8 ? DBX_CONV_WFRAG : 0);
+#ifdef BAND_TS
+            // -DBAND_TS: the band kernel stamps the shader clock around its stage barrier (three per stage and wave): how long a wave waits for
+            // its loads, for the barrier, and how long its three taps take -- per half of the workgroup's waves
+            unsigned long long* tsb; CK(hipMalloc(&tsb, 64 * 16 * 64 * 3 * 8)); CK(hipMemset(tsb, 0, 64 * 16 * 64 * 3 * 8));
+            int rc = conv_forward_t<__bf16>(&d, &xv, wuse, bias, &yv, (S.epi & DBX_EPI_GATE) ? &gv : nullptr, nullptr, 0, st, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, (float*)tsb);
+            CK(hipStreamSynchronize(st));
+            {
+                std::vector<unsigned long long> h(64 * 16 * 64 * 3);
+                CK(hipMemcpy(h.data(), tsb, h.size() * 8, hipMemcpyDeviceToHost));
+                const int NWV = 8;
+                for (int wg : {0, 9, 33}) for (int wv : {0, 5}) {
+                    const unsigned long long* t = h.data() + ((size_t)wg * NWV + wv) * 64 * 3;
+                    double sw = 0, sb = 0, sc = 0; int n = 0;
+                    for (int ks = 0; ks < 63 && t[(ks + 1) * 3]; ++ks) { sw += t[ks * 3 + 1] - t[ks * 3]; sb += t[ks * 3 + 2] - t[ks * 3 + 1]; sc += t[(ks + 1) * 3] - t[ks * 3 + 2]; ++n; }
+                    if (n) printf("    wg %2d wave %d, mean of %d stages: load wait %.0f  barrier wait %.0f  three taps %.0f  (sum %.0f clocks; the stage's MFMAs of both waves of a SIMD: 3072)\n", wg, wv, n, sw / n, sb / n, sc / n, (sw + sb + sc) / n);
+                }
+            }
+            CK(hipFree(tsb));
+            if (rc) printf("  variant %d: error %s\n", v, g_err);
+            continue;                                       // (the stamped kernel writes through a.part: no un-stamped timing runs)
+#else
             int rc = conv_forward_t<__bf16>(&d, &xv, wuse, bias, &yv, (S.epi & DBX_EPI_GATE) ? &gv : nullptr, nullptr, 0, st);
+#endif
             if (rc) { printf("  variant %d: error %s\n", v, g_err); continue; }
             CK(hipStreamSynchronize(st));
             gather_out<<<(nout + 255) / 256, 256, 0, st>>>(y0, got, S.h, S.w, S.co, (int)pix.size(), dpix);
