@@ -1607,6 +1607,8 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
                 DBX_SELECT_WS(256, 256, 1, 1, 1, (nfx == 4 ? launch_conv_ws<T, 1, 1, 1, 4>(a, x->n, x->h, x->pad, s) : launch_conv_ws<T, 1, 1, 1>(a, x->n, x->h, x->pad, s)));
             }
             DBX_REQUIRE(!a.w2f, "heads forward fused: needs the fixed bias + hash-dropout epilogue of the 1x1 ws kernel");
+            // (128-pixel tiles with two workgroups per CU for the 3x3 instantiation: measured 3-6 % SLOWER in the lab -- twice the weight and
+            //  band traffic per MFMA, and its K loop is 97 % of the tile: there is no epilogue worth overlapping)
             if (k1) DBX_SELECT_WS(256, 256, 1, 1, 0, (launch_conv_ws<T, 1, 1>(a, x->n, x->h, x->pad, s)));
             if (wm == 1) DBX_SELECT_WS(256, 256, 1, 3, 0, (launch_conv_ws<T, 1, 3>(a, x->n, x->h, 1, s)));
             DBX_SELECT_WS(512, 128, 2, 3, 0, (launch_conv_ws<T, 2, 3>(a, x->n, x->h, 1, s)));
