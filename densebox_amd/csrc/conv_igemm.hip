@@ -540,7 +540,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
 // (the measured limiter of v2), and a third of the barriers.  Pieces (1 KiB = 16 rows x 64 B) are dealt round-robin to
 // the 8 waves; the source-side XOR swizzle and the counted-vmcnt ring are as in v2.
 template <typename T, int BM, int BN, int STAGES, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void conv3x3_band_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv3x3_band_kernel(const ConvArgs a) {
     constexpr int BKB = 64, AR = BM + 16;
     constexpr int NW = WM * WN;                                         // waves: 8 (two per SIMD) or 16 (four per SIMD, 128 registers each)
     constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -1644,6 +1644,12 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
 #ifdef DBX_LAB
             if (conv_variant() == 5 && (d->cin_pad * ES) % 128 == 0) return launch_conv_pipe<T, 5>(a, s);
             if (conv_variant() == 7 && (d->cin_pad * ES) % 128 == 0) return launch_conv_pw4<T, 0>(a, s);
+#endif
+#ifdef DBX_LAB
+            if (conv_variant() == 30) {            // two 4-wave workgroups per CU (independent barrier domains): 240 x 128 tiles, 80 KB of LDS each
+                a.ntile_n = y->c / 128; a.nblocks = (int)((Q + 239) / 240) * a.ntile_n;
+                return launch_conv_band<T, 240, 128, 2, 1, 4>(a, s);
+            }
 #endif
             DBX_SELECT(DBX_K_BAND, 256, 256, "conv3x3_band_kernel", (launch_conv_band<T, 256, 256, 2, 2, 4>(a, s)));
         }
