@@ -107,6 +107,69 @@ __device__ __forceinline__ unsigned dbx_drop_bits4(unsigned seed, unsigned m, un
     return (dbx_drop_hash32(seed, m, c4 >> 3) >> ((c4 & 7u) * 4u)) & 15u;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T> struct Mma32;
+template <> struct Mma32<_Float16> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma32<__bf16> {
+    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+// The heads' hidden gradient as its consumers GENERATE it (round 4: dbx_heads_backward_gen_*): d_hid = keep * scale * (d_out W2) with
+// d_out of <= 8 channels per head -- a 32-channel x 32-pixel tile of it is ONE v_mfma_f32_32x32x16 (A = scale * W2^T [32 ch x 8 k, the
+// upper K half zero], B = d_out^T [8 k x 32 px]) plus one hash per lane: D[i][j] has lane j = pixel, 16 channels i = 8 (r / 4) +
+// 4 (lane / 32) + r % 4 -- all inside the 32-channel block one dbx_drop_hash32 covers.  W2 and d_out are rounded to the compute dtype
+// (the forward's second convs use the same rounded W2); the products are exact in fp32, the sum of <= 8 of them is the MFMA's.
+struct GenHid {
+    const char* dout;            // [N * H * W][ld] compute dtype, pad 0; one slot of >= 8 channels per head, channels >= k are zero
+    const float* w2[4];          // fp32 [k][512] per head (conv5_2 weights)
+    int k[4];
+    int ld, slot, nh;            // elements per pixel / per head slot
+    int H, W, pad;               // the hidden map; pad: of the frame the consumer walks (d_out itself has none)
+    unsigned seed; int use_hash; // use_hash 0: no dropout (scale 1), 1: keep bits of dbx_drop_hash32 (scale 2)
+};
+// A operand of the generating MFMA for the row `ch` (channel inside head hd) this lane holds; lanes >= 32 (K 8..15) hold zeros
+template <typename T>
+__device__ __forceinline__ u32x4 genhid_wfrag(const GenHid& gh, int hd, int ch, int lane) {
+    const float* wp = gh.w2[0];
+    int k = gh.k[0];
+#pragma unroll
+    for (int hh = 1; hh < 4; ++hh)
+        if (hd == hh && gh.w2[hh]) { wp = gh.w2[hh]; k = gh.k[hh]; }
+    const float sc = gh.use_hash ? 2.f : 1.f;
+    u32x4 raw;
+    T* e = (T*)&raw;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = j < k ? j : (k > 0 ? k - 1 : 0);
+        const float v = wp[(size_t)row * 512 + ch];
+        e[j] = from_f32<T>((lane < 32 && j < k) ? v * sc : 0.f);
+    }
+    return raw;
+}
+// pixel of frame position q (inside one image's frame, row-major over wp columns): compact index m = (img * H + y) * W + x, or -1 in the halo
+__device__ __forceinline__ int genhid_pixel(const GenHid& gh, int img, int q_in_img, int wp, float inv_wp) {
+    const int fy = (int)(((float)q_in_img + 0.5f) * inv_wp);         // exact: (q + 0.5) / wp is >= 0.5 / wp away from an integer
+    const int fx = q_in_img - fy * wp;
+    const int y = fy - gh.pad, x = fx - gh.pad;
+    return ((unsigned)y < (unsigned)gh.H && (unsigned)x < (unsigned)gh.W) ? (img * gh.H + y) * gh.W + x : -1;
+}
+// B operand: the pixel's d_out slot (16 bytes) in the lower lane half, zeros in the upper one and for halo pixels.  The load is
+// unconditional (halo pixels read pixel 0) and the zeroing happens where the value is consumed: a select behind the load would wait for it
+__device__ __forceinline__ u32x4 genhid_load_dout(const GenHid& gh, int hd, int m) {
+    const int mm = m < 0 ? 0 : m;
+    return *(const u32x4*)(gh.dout + ((size_t)mm * gh.ld + hd * gh.slot) * 2);
+}
+__device__ __forceinline__ u32x4 genhid_bfrag(const u32x4& raw, int m, int lane) {
+    return (m < 0 || lane >= 32) ? (u32x4){0u, 0u, 0u, 0u} : raw;
+}
+
 // Fragment-order weight image (conv3x3_ws.hpp; dbx_pack_weight modes 4/5).  One 1-KiB block = the A operand of one v_mfma_f32_32x32x16:
 // [lane = 32 * ((k % 16) / 8) + row % 32][k % 8]; blocks ordered [row / BN][period][step][(row % BN) / 32] with
 //   3x3: period = 3 * (k / 64) + ky,  step = kx * 4 + (k % 64) / 16   (tap = 3 ky + kx; 12 steps per period; the three ky

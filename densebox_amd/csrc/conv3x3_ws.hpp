@@ -27,22 +27,6 @@
 //   compiler-scheduled epilogue (vmcnt(0) on both sides).
 #pragma once
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-template <typename T> struct Mma32;
-template <> struct Mma32<_Float16> {
-    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-    }
-};
-template <> struct Mma32<__bf16> {
-    static __device__ __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-    }
-};
-
-
-
 namespace ws {
 // weight loads run D steps ahead of their MFMAs.  Round 4: 3 steps for the 1x1 GEMMs with 256-pixel tiles (their ring of four register
 // sets has room for it): a K = 16 step of 16 MFMAs is ~512 cycles, an L2 hit ~500-800 ns -- two steps ahead was short of it

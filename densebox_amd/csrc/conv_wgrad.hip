@@ -767,11 +767,24 @@ __global__ __launch_bounds__(512) void wgrad_all9_kernel(const WgradArgs a) {
 // rows of each image (a 1x1 tap needs no halo rows).  The bias partial comes from ones-MFMAs of the waves' dz fragments (wave
 // column wn takes fragments 2 wn, 2 wn + 1) in the steps assigned to the workgroup's ci tile.
 // Requires dz_c % 256 == 0, x_c % 256 == 0.  Grid: (co-tile, ci-tile) x split-K; bias partial rows = splits * tiles_ci.
-template <typename T>
-__global__ __launch_bounds__(512) void wgrad_wide2_kernel(const WgradArgs a) {
+// GEN (round 4, dbx_heads1_wgrad_gen): the dz tile is not loaded but GENERATED -- dz = the heads' hidden gradient d_hid = keep * (d_out W2)
+// (common.hpp: GenHid): per step wave w owns the 32 hidden channels 32 w .. 32 w + 31 of the tile's 32 pixel rows: one
+// v_mfma_f32_32x32x16 on the pixels' d_out slots (loaded two steps ahead: 16 bytes per lane, after the step's two x pieces in the vmcnt
+// order), one hash per lane, 16 selects, four ds_write_b64 into the stage the DMA version fills.  The generated tile's LDS map XORs the
+// row bits 2 and 4 into address bits 3 and 4 on top of swz16w's (swzg): the 32 lanes of a write hold 32 different rows of ONE column --
+// 32 different 8-byte bank pairs instead of 8 -- and the transposing reads keep their two-pass pattern.  The 944 MB hidden gradient is
+// never read (nor written, once the data-gradient GEMM generates it too).
+__device__ __forceinline__ int swzg(int r, int b) {
+    return r * 512 + (b ^ (((r & 3) << 5) | (((r >> 3) & 1) << 7) | (((r >> 2) & 1) << 3) | (((r >> 4) & 1) << 4)));
+}
+#ifndef GEN_ABL
+#define GEN_ABL 0                                                       // lab builds: 1 no mask + store, 2 no generating MFMA, 4 no d_out fetch
+#endif
+template <typename T, bool GEN = false>
+__global__ __launch_bounds__(512) void wgrad_wide2_kernel(const WgradArgs a, const GenHid gh) {
     static_assert(sizeof(T) == 2, "16-bit tiles");
     constexpr int R = 32, T_BYTES = R * 512, STAGE = 2 * T_BYTES, NST = 4;
-    constexpr int SLOTS = 4;                                            // 32 pieces of 1 KiB (2 rows) per stage, 8 waves
+    constexpr int SLOTS = GEN ? 3 : 4;                                  // loads per wave and step: 32 pieces of 1 KiB (2 rows) per stage over 8 waves; GEN: two x pieces + one d_out slot
     extern __shared__ __attribute__((aligned(16))) char smem[];        // 4 x 32 KB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -812,8 +825,10 @@ __global__ __launch_bounds__(512) void wgrad_wide2_kernel(const WgradArgs a) {
     };
 #define WIDE2_ISSUE(sb)                                                                     \
     do {                                                                                    \
-        glds(ap + sA0, vA, ldsw + (sb));                                                    \
-        glds(ap + sA1, vA, ldsw + (sb) + 8 * 1024);                                         \
+        if (!GEN) {                                                                         \
+            glds(ap + sA0, vA, ldsw + (sb));                                                \
+            glds(ap + sA1, vA, ldsw + (sb) + 8 * 1024);                                     \
+        }                                                                                   \
         glds(bp + sB0, vB, ldsw + (sb) + T_BYTES);                                          \
         glds(bp + sB1, vB, ldsw + (sb) + T_BYTES + 8 * 1024);                               \
         if (++issued < nsteps) {                                                            \
@@ -821,6 +836,83 @@ __global__ __launch_bounds__(512) void wgrad_wide2_kernel(const WgradArgs a) {
             else { ap += aR; bp += bR; }                                                    \
         }                                                                                   \
     } while (0)
+
+    // ---- GEN: the d_out slots of the tiles two steps ahead, the generating MFMA's A operand, the walk of the fetches.  The walk is
+    // incremental (a frame position 32 further on is the same row or the next one: wp >= 32): no division, no 32-bit multiply per step
+    // (this kernel's VALU instructions are not hidden by the other wave's MFMAs: both waves of a SIMD generate behind the same barrier --
+    // 190 of them per step cost 0.6 us of a 1.0 us step in the first version)
+    __shared__ u32x2 glut[16];                                          // keep nibble -> masks of two packed 16-bit pairs
+    const int ghd = (tile_co * 256) / 512, gc32 = tile_co * 8 + wave;  // head of the tile's hidden channels; the wave's 32-channel block (hash index)
+    u32x4 gw = {0u, 0u, 0u, 0u}, dq[2];
+    int dm[2] = {-1, -1};
+    unsigned dh[2] = {0u, 0u};                                          // m * 0x9E3779B1 of the slots' pixels
+    int fimg = 0, fij = 0, fissued = 0;
+    int gfx0 = 0, gy0 = 0, gfx = 0, gy = 0, gm = 0;                     // frame column / map row of the lane's pixel in the next tile to fetch, its compact index
+    unsigned ghm = 0u;
+    const int gdw = 32 - a.wp + gh.W;                                   // compact-index step when the walk wraps into the next frame row
+    const unsigned gh32 = 32u * 0x9E3779B1u, ghw = (unsigned)gdw * 0x9E3779B1u, gcc = gh.seed ^ ((unsigned)gc32 * 0x85EBCA77u);
+    const unsigned ld2 = (unsigned)gh.ld * 2u, goff = (unsigned)(ghd * gh.slot) * 2u;
+    int glc = 0;                                                        // lane constant: compact index of the lane's pixel in image 0's first tile
+    unsigned glh = 0u;
+    const unsigned gimg_h = (unsigned)(gh.H * gh.W) * 0x9E3779B1u;
+    if constexpr (GEN) {
+        if (tid < 16) glut[tid] = (u32x2){((tid & 1) ? 0xffffu : 0u) | ((tid & 2) ? 0xffff0000u : 0u), ((tid & 4) ? 0xffffu : 0u) | ((tid & 8) ? 0xffff0000u : 0u)};
+        gw = genhid_wfrag<T>(gh, ghd, (tile_co * 256) % 512 + 32 * wave + (lane & 31), lane);
+        fimg = gs0 / a.spi; fij = gs0 - fimg * a.spi;
+        const int q0l = a.row0 + (lane & 31);                           // the lane's frame position in an image's first tile
+        const int fy0 = q0l / a.wp;
+        gfx0 = q0l - fy0 * a.wp; gy0 = fy0 - gh.pad;
+        glc = gy0 * gh.W + gfx0 - gh.pad; glh = (unsigned)glc * 0x9E3779B1u;
+        gfx = gfx0; gy = gy0; gm = fimg * gh.H * gh.W + glc; ghm = (unsigned)fimg * gimg_h + glh;
+        for (int t = 0; t < fij; ++t) {                                 // (a split that starts inside an image: once per workgroup)
+            gfx += 32; gm += 32; ghm += gh32;
+            if (gfx >= a.wp) { gfx -= a.wp; ++gy; gm += gdw - 32; ghm += ghw - gh32; }
+        }
+        __syncthreads();
+    }
+    // the slot load is inline asm like the LDS-DMA pieces: the compiler's own wait for a load it tracks is vmcnt(0) in front of the
+    // generating MFMA -- behind the two x pieces just issued, a full memory latency per step
+    auto gfetch = [&](int j) {
+        const bool valid = (unsigned)gy < (unsigned)gh.H && (unsigned)(gfx - gh.pad) < (unsigned)gh.W;
+        const unsigned voff = __umul24((unsigned)(valid ? gm : 0), ld2) + goff;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dq[j]) : "v"(voff), "s"(gh.dout) : "memory");
+        dm[j] = valid ? gm : -1; dh[j] = ghm;
+        // advance to the next tile (branch-free: uniform selects; the last tiles of a split re-fetch its last tile)
+        ++fissued;
+        const bool adv = fissued < nsteps, newimg = adv && fij + 1 == a.spi;
+        fij = newimg ? 0 : (adv ? fij + 1 : fij);
+        fimg += newimg ? 1 : 0;
+        const int nx = gfx + 32;
+        const bool wrap = nx >= a.wp;
+        const int sx = wrap ? nx - a.wp : nx, sy = gy + (wrap ? 1 : 0), sm = gm + (wrap ? gdw : 32);
+        const unsigned sh = ghm + (wrap ? ghw : gh32);
+        gfx = newimg ? gfx0 : (adv ? sx : gfx);
+        gy = newimg ? gy0 : (adv ? sy : gy);
+        gm = newimg ? fimg * gh.H * gh.W + glc : (adv ? sm : gm);
+        ghm = newimg ? (unsigned)fimg * gimg_h + glh : (adv ? sh : ghm);
+    };
+    f32x16 gd;
+    auto ggen_mma = [&](int j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gd[r] = 0.f;
+        Mma32<T>::run(gw, genhid_bfrag(dq[j], dm[j], lane), gd);           // (dq[j] is tied to the counted wait in front of the barrier)
+    };
+    auto ggen_store = [&](unsigned sb, int j) {
+        const f32x16 d = gd;
+        unsigned x = gcc ^ dh[j];                                       // dbx_drop_hash32 with its two products precomputed (branch-free: no dropout = all bits)
+        x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+        const unsigned bits = (x >> (4 * (lane >> 5))) | (gh.use_hash ? 0u : 0xffffffffu);
+        char* row = smem + sb;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const u32x2 mk = glut[(bits >> (8 * b)) & 15u];
+            typedef float f32x2v __attribute__((ext_vector_type(2)));
+            typedef T t2v __attribute__((ext_vector_type(2)));
+            const unsigned p0 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v){d[4 * b], d[4 * b + 1]}, t2v));
+            const unsigned p1 = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v){d[4 * b + 2], d[4 * b + 3]}, t2v));
+            *(u32x2*)(row + swzg(lane & 31, (32 * wave + 8 * b + 4 * (lane >> 5)) * 2)) = (u32x2){p0 & mk.x, p1 & mk.y};
+        }
+    };
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -838,7 +930,7 @@ __global__ __launch_bounds__(512) void wgrad_wide2_kernel(const WgradArgs a) {
     };
     auto rdA = [&](const char* Sb, int mi) {
         const int r0 = 8 * g + rsub, cbyte = (wm * 64 + mi * 16) * 2 + csub;
-        const u32x2 lo = trd(Sb + swz16w(r0, cbyte)), hi = trd(Sb + swz16w(r0 + 4, cbyte));
+        const u32x2 lo = trd(Sb + (GEN ? swzg(r0, cbyte) : swz16w(r0, cbyte))), hi = trd(Sb + (GEN ? swzg(r0 + 4, cbyte) : swz16w(r0 + 4, cbyte)));
         return (u32x4){lo.x, lo.y, hi.x, hi.y};
     };
     auto rdB = [&](const char* Sb, int ni) {
@@ -858,7 +950,18 @@ __global__ __launch_bounds__(512) void wgrad_wide2_kernel(const WgradArgs a) {
         WIDE2_ISSUE(0u);
         WIDE2_ISSUE((unsigned)STAGE);
         WIDE2_ISSUE((unsigned)(2 * STAGE));
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SLOTS) : "memory");
+        if constexpr (GEN) {                                            // tiles 0..2 (cold start: their d_out loads are waited for one by one)
+            gfetch(0); gfetch(1);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(dq[0]), "+v"(dq[1]) :: "memory");
+            ggen_mma(0); ggen_store(0u, 0); ggen_mma(1); ggen_store((unsigned)STAGE, 1);
+            gfetch(0);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(dq[0]) :: "memory");
+            ggen_mma(0); ggen_store((unsigned)(2 * STAGE), 0);
+            gfetch(1); gfetch(0);                                       // tiles 3 and 4
+            asm volatile("s_waitcnt vmcnt(1)" : "+v"(dq[1]) :: "memory");   // (tile 3's slot: the loop's counted wait assumes x pieces behind it)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SLOTS) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -877,12 +980,17 @@ __global__ __launch_bounds__(512) void wgrad_wide2_kernel(const WgradArgs a) {
         for (int u = 0; u < 8; ++u) {
             if (u == 5) {
                 // tile s+1 has landed (this wave's pieces; the barrier covers the others'), every wave is past tile s-1
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
+                if constexpr (GEN) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dq[NXT]) : "n"(SLOTS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
                 WIDE2_ISSUE(po);                                        // tile s + 3
+                if constexpr (GEN && !(GEN_ABL & 2)) ggen_mma(NXT);     // its dz half from the slot fetched two steps ago ...
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (GEN) {
+                if (u == 7) { if (!(GEN_ABL & 1)) ggen_store(po, NXT); if (!(GEN_ABL & 4)) gfetch(NXT); }       // ... masked and written under the step's last MFMAs; tile s + 5's slot
             }
             const u32x4 b = bf[u & 1];
             if (u < 7) bf[(u + 1) & 1] = rdB(Sb, u + 1);
@@ -1667,7 +1775,7 @@ extern "C" int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_
 
 template <typename T>
 static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cpad, int co, int ci, float* dw, float* db,
-                   void* scratch, int accumulate, hipStream_t s, int ci_total, int ci_off) {
+                   void* scratch, int accumulate, hipStream_t s, int ci_total, int ci_off, const GenHid* gen = nullptr) {
     DBX_REQUIRE(ci_off >= 0 && ci_off + ci <= ci_total, "wgrad: column slice [%d, %d) outside the %d input channels of dw", ci_off, ci_off + ci, ci_total);
     constexpr int ES = sizeof(T);
     DBX_REQUIRE(dz->n == x->n && dz->h + 2 * dz->pad == x->h + 2 * x->pad && dz->w + 2 * dz->pad == x->w + 2 * x->pad,
@@ -1690,15 +1798,24 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.hp = a.nstrips = a.units = a.units_per_split = 0;
     a.spi = p.spi; a.img_rows = (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad); a.row0 = (dz->w + 2 * dz->pad) * dz->pad;
     a.steps_total = p.steps_total; a.steps_per_split = p.steps_per_split;
+    DBX_REQUIRE(!gen || (p.wide2 && p.spi > 0 && sizeof(T) == 2), "wgrad with a generated hidden gradient: needs the wide 1x1 kernel on padded frames of >= 32 columns");
     if (p.wide2) {
         if constexpr (sizeof(T) == 2) {
             constexpr int smem = 4 * 2 * 32 * 512;
-            static DbxDevOnce attr_once; int attr_dev = 0;
-            if (attr_once.pending(&attr_dev)) {
-                DBX_HIP(hipFuncSetAttribute((const void*)wgrad_wide2_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                attr_once.mark(attr_dev);
+            static DbxDevOnce attr_once, attr_once_g; int attr_dev = 0;
+            if (gen) {
+                if (attr_once_g.pending(&attr_dev)) {
+                    DBX_HIP(hipFuncSetAttribute((const void*)wgrad_wide2_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                    attr_once_g.mark(attr_dev);
+                }
+                hipLaunchKernelGGL((wgrad_wide2_kernel<T, true>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a, *gen);
+            } else {
+                if (attr_once.pending(&attr_dev)) {
+                    DBX_HIP(hipFuncSetAttribute((const void*)wgrad_wide2_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                    attr_once.mark(attr_dev);
+                }
+                hipLaunchKernelGGL((wgrad_wide2_kernel<T, false>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a, GenHid{});
             }
-            hipLaunchKernelGGL((wgrad_wide2_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a);
         }
     } else if (p.all9) {
         if constexpr (sizeof(T) == 2) {
@@ -1798,4 +1915,40 @@ extern "C" int dbx_conv_wgrad_slice(int32_t dtype, const dbx_view* dz, const dbx
                                     int32_t accumulate, void* stream) {
     if (!dz || !x || !dw_oihw || !scratch) { dbx_set_error("wgrad: null argument"); return DBX_ERR_ARG; }
     DBX_DISPATCH_DTYPE(dtype, wgrad_t, dz, x, kh, kw, cpad, co, ci, dw_oihw, db, scratch, accumulate, (hipStream_t)stream, dw_ci_total, dw_ci_off);
+}
+
+// ---------------------------------------------------------------------------------------------- heads: dW1 with the hidden gradient generated
+// dbx_heads1_wgrad_gen: dbx_conv_wgrad_slice(d_hid, x, 1x1) for the heads' first convs WITHOUT d_hid in memory: d_hid = keep * (d_out W2)
+// is generated tile by tile inside wgrad_wide2_kernel<T, true> (common.hpp: GenHid).  d_out: the compact [N, H, W] map of the heads'
+// output gradients (pad 0, one slot of slot_c >= 8 channels per head, channels >= k[i] zero); x: the 1x1 convs' input on its padded
+// frame (pad >= 1, >= 32 columns); w2[i]: fp32 [k[i]][512].  use_hash / drop_seed: the forward's hash dropout (0: no dropout).
+// Scratch: dbx_conv_wgrad_scratch_bytes for a dz view of 512 * nh channels congruent with x.
+template <typename T>
+static int heads1_wgrad_gen_t(const dbx_view* d_out, const dbx_view* x, const float* const* w2, const int32_t* k, int nh, int use_hash, unsigned seed,
+                              int ci, float* dw, int ci_total, int ci_off, float* db, void* scratch, hipStream_t s) {
+    if constexpr (sizeof(T) != 2) { dbx_set_error("heads1_wgrad_gen: 16-bit compute types only"); return DBX_ERR_DTYPE; }
+    else {
+        DBX_REQUIRE(nh >= 1 && nh <= 4 && d_out->pad == 0 && d_out->n == x->n && d_out->h == x->h && d_out->w == x->w && x->pad >= 1,
+                    "heads1_wgrad_gen: d_out is the compact map of x's pixels, x a padded frame");
+        DBX_REQUIRE(d_out->c % nh == 0 && d_out->c / nh >= 8 && ((size_t)d_out->ptr % 16) == 0 && (d_out->ld * 2) % 16 == 0 && (d_out->c_off * 2) % 16 == 0 &&
+                    ((d_out->c / nh) * 2) % 16 == 0, "heads1_wgrad_gen: d_out slots of >= 8 channels, 16-byte aligned");
+        DBX_REQUIRE((int64_t)d_out->n * d_out->h * d_out->w * d_out->ld * 2 < ((int64_t)1 << 31), "heads1_wgrad_gen: d_out beyond 2 GiB");
+        GenHid g;
+        g.dout = (const char*)d_out->ptr + (size_t)d_out->c_off * 2;
+        for (int i = 0; i < 4; ++i) {
+            g.w2[i] = i < nh ? w2[i] : nullptr; g.k[i] = i < nh ? k[i] : 0;
+            if (i < nh) DBX_REQUIRE(w2[i] && k[i] >= 1 && k[i] <= 8, "heads1_wgrad_gen: k in 1..8");
+        }
+        g.ld = d_out->ld; g.slot = d_out->c / nh; g.nh = nh; g.H = x->h; g.W = x->w; g.pad = x->pad; g.seed = seed; g.use_hash = use_hash ? 1 : 0;
+        dbx_view dz = *x;                                   // the virtual hidden gradient: congruent with x, 512 * nh channels, never dereferenced
+        dz.c = dz.ld = 512 * nh; dz.c_off = 0;
+        return wgrad_t<T>(&dz, x, 1, 1, 0, 512 * nh, ci, dw, db, scratch, 0, s, ci_total, ci_off, &g);
+    }
+}
+extern "C" int dbx_heads1_wgrad_gen(int32_t dtype, const dbx_view* d_out, const dbx_view* x, const float* const* w2, const int32_t* k, int32_t nh,
+                                    int32_t use_hash, uint32_t drop_seed, int32_t ci, float* dw_oihw, int32_t dw_ci_total, int32_t dw_ci_off,
+                                    float* db, void* scratch, void* stream) {
+    if (!d_out || !x || !w2 || !k || !dw_oihw || !scratch) { dbx_set_error("heads1_wgrad_gen: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(dtype, heads1_wgrad_gen_t, d_out, x, w2, k, nh, use_hash, (unsigned)drop_seed, ci, dw_oihw, dw_ci_total, dw_ci_off, db, scratch,
+                       (hipStream_t)stream);
 }

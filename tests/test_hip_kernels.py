@@ -918,3 +918,40 @@ def test_heads_forward_fused_equals_the_two_gemms(ks, n, h, w, dtn):
     # about half of the hidden map is dropped, the rest doubled: the dropout bits are live
     frac = float((ta == 0).float().mean())
     assert 0.35 < frac < 0.85, frac
+
+
+@pytest.mark.parametrize('dtn', ['f16', 'bf16'])
+@pytest.mark.parametrize('drop', ['hash', 'none'])
+@pytest.mark.parametrize('geom', [(3, 60, 60), (2, 23, 37), (5, 12, 30)])
+def test_heads1_wgrad_gen_equals_wgrad_of_the_materialised_hidden_gradient(geom, drop, dtn):
+    """dbx_heads1_wgrad_gen (d_hid = keep * (d_out W2) generated inside the weight-gradient kernel) against dbx_head2_dgrad into memory +
+    dbx_conv_wgrad_slice on it.  W2 is pre-rounded to the compute dtype (the generating MFMA takes it in that dtype), so the two hidden
+    gradients differ only where the fp32 sum of <= 8 exact products rounds differently: dW1 / db1 agree to fp32-sum tolerance."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    n, h, w = geom
+    ks = [1, 4, 4, 8]
+    nh = len(ks)
+    g = torch.Generator(device='cpu').manual_seed(5 + h)
+    dout = torch.zeros(n, 8 * nh, h, w)
+    for i, k in enumerate(ks):
+        dout[:, 8 * i:8 * i + k] = torch.randn(n, k, h, w, generator=g)
+    w2 = [(torch.randn(k, 512, generator=g) * 0.05).to(tdt).float().cuda().contiguous() for k in ks]
+    x = torch.randn(n, 256, h, w, generator=g)
+    fo, to, dv = framed(dout, 0, tdt)
+    fx, tx, xv = framed(x, 1, tdt)
+    fd, td, dhv = framed(torch.zeros(n, 512 * nh, h, w), 1, tdt)
+    use_hash, seed = (1, 0xBEEF) if drop == 'hash' else (0, 0)
+    karr = (C.c_int32 * nh)(*ks)
+    wp = (C.c_void_p * nh)(*[t.data_ptr() for t in w2])
+    check(L.dbx_head2_dgrad(dt, C.byref(dv), wp, karr, nh, C.byref(dhv), None, 512 * nh, use_hash, seed, stream_ptr()))
+    sc = torch.empty(L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dhv), C.byref(xv), 1, 1), dtype=torch.uint8, device='cuda')
+    dw1 = torch.full((512 * nh, 300, 1, 1), 7.0, device='cuda'); db1 = torch.full((512 * nh,), 7.0, device='cuda')
+    dw2 = torch.full((512 * nh, 300, 1, 1), 7.0, device='cuda'); db2 = torch.full((512 * nh,), 7.0, device='cuda')
+    check(L.dbx_conv_wgrad_slice(dt, C.byref(dhv), C.byref(xv), 1, 1, 0, 512 * nh, 256, ptr(dw1), 300, 44, ptr(db1), ptr(sc), 0, stream_ptr()))
+    check(L.dbx_heads1_wgrad_gen(dt, C.byref(dv), C.byref(xv), wp, karr, nh, use_hash, seed, 256, ptr(dw2), 300, 44, ptr(db2), ptr(sc), stream_ptr()))
+    torch.cuda.synchronize()
+    assert float(dw1[:, 44:300].abs().sum()) > 0 and torch.equal(dw1[:, :44], dw2[:, :44])
+    sw, sb = float(dw1[:, 44:300].abs().max()), float(db1.abs().max())
+    assert float((dw1 - dw2).abs().max()) <= 2e-4 * sw, (float((dw1 - dw2).abs().max()), sw)
+    assert float((db1 - db2).abs().max()) <= 2e-4 * sb, (float((db1 - db2).abs().max()), sb)
