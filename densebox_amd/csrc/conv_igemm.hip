@@ -1433,6 +1433,7 @@ static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s
 }
 
 #include "conv3x3_c64p.hpp"
+#include "heads_gen.hpp"
 
 static int ws_level() {              // DBX_WS=0 keeps the LDS band kernels on every layer, 2 plans ws wherever it can run (A/B testing)
     static int v = -1;
@@ -1943,4 +1944,43 @@ extern "C" int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw,
                                int32_t k_off, void* stream) {
     DBX_DISPATCH_DTYPE(dtype, pack_weight_t, mode, w_oihw, co, ci, kh, kw, w_packed, rows_pad, cin_pad, row_off, k_off,
                        (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------- heads: d_x with the hidden gradient generated
+// dbx_heads1_dgrad_gen: the ReLU-gated data gradient of the heads' first 1x1 convs, d_x = gate(x) * (W1^T d_hid), with d_hid = keep *
+// (d_out W2) generated in registers (heads_gen.hpp) -- dbx_conv_forward(d_hid, W1^T image, DBX_EPI_GATE) without d_hid in memory.
+// d_out / w2 / k / use_hash / drop_seed as for dbx_heads1_wgrad_gen; w1t_frag: dbx_pack_weight mode 5 image of W1 restricted to the
+// 256 input channels of y (rows_pad 256, cin_pad 512 nh); y, gate: 256-channel views of the same pixels (any padding).
+template <typename T>
+static int heads1_dgrad_gen_t(const dbx_view* d_out, const float* const* w2, const int32_t* k, int nh, int use_hash, unsigned seed, const void* w1t_frag,
+                              const dbx_view* y, const dbx_view* gate, hipStream_t s) {
+    if constexpr (sizeof(T) != 2) { dbx_set_error("heads1_dgrad_gen: 16-bit compute types only"); return DBX_ERR_DTYPE; }
+    else {
+        DBX_REQUIRE(nh >= 1 && nh <= 4 && d_out->pad == 0 && d_out->n == y->n && d_out->h == y->h && d_out->w == y->w && gate->n == y->n &&
+                    gate->h == y->h && gate->w == y->w, "heads1_dgrad_gen: d_out (compact), y and gate are maps of the same pixels");
+        DBX_REQUIRE(y->c == 256 && gate->c == 256 && (y->ld * 2) % 16 == 0 && (gate->ld * 2) % 16 == 0 && (y->c_off * 2) % 16 == 0 && (gate->c_off * 2) % 16 == 0 &&
+                    ((size_t)y->ptr % 16) == 0 && ((size_t)gate->ptr % 16) == 0 && ((size_t)w1t_frag % 16) == 0, "heads1_dgrad_gen: 256 output channels, 16-byte aligned");
+        DBX_REQUIRE(d_out->c % nh == 0 && d_out->c / nh >= 8 && ((size_t)d_out->ptr % 16) == 0 && (d_out->ld * 2) % 16 == 0 && (d_out->c_off * 2) % 16 == 0 &&
+                    ((d_out->c / nh) * 2) % 16 == 0, "heads1_dgrad_gen: d_out slots of >= 8 channels, 16-byte aligned");
+        const int64_t npix = (int64_t)y->n * y->h * y->w;
+        DBX_REQUIRE(npix > 0 && npix < (1 << 24) && npix * d_out->ld * 2 < ((int64_t)1 << 32), "heads1_dgrad_gen: pixel count");
+        HGenArgs a;
+        a.g.dout = (const char*)d_out->ptr + (size_t)d_out->c_off * 2;
+        for (int i = 0; i < 4; ++i) {
+            a.g.w2[i] = i < nh ? w2[i] : nullptr; a.g.k[i] = i < nh ? k[i] : 0;
+            if (i < nh) DBX_REQUIRE(w2[i] && k[i] >= 1 && k[i] <= 8, "heads1_dgrad_gen: k in 1..8");
+        }
+        a.g.ld = d_out->ld; a.g.slot = d_out->c / nh; a.g.nh = nh; a.g.H = y->h; a.g.W = y->w; a.g.pad = 0; a.g.seed = seed; a.g.use_hash = use_hash ? 1 : 0;
+        a.w1f = (const char*)w1t_frag;
+        a.y = (char*)y->ptr + (size_t)y->c_off * 2; a.gate = (const char*)gate->ptr + (size_t)gate->c_off * 2;
+        a.y_hp = y->h + 2 * y->pad; a.y_wp = y->w + 2 * y->pad; a.y_ld = y->ld; a.y_pad = y->pad;
+        a.g_hp = gate->h + 2 * gate->pad; a.g_wp = gate->w + 2 * gate->pad; a.g_ld = gate->ld; a.g_pad = gate->pad;
+        a.npix = (int)npix; a.ntiles = (int)((npix + 255) / 256); a.nhb = 16 * nh;
+        return launch_heads1_dgrad_gen<T>(a, s);
+    }
+}
+extern "C" int dbx_heads1_dgrad_gen(int32_t dtype, const dbx_view* d_out, const float* const* w2, const int32_t* k, int32_t nh, int32_t use_hash,
+                                    uint32_t drop_seed, const void* w1t_frag, const dbx_view* y, const dbx_view* gate, void* stream) {
+    if (!d_out || !w2 || !k || !w1t_frag || !y || !gate) { dbx_set_error("heads1_dgrad_gen: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(dtype, heads1_dgrad_gen_t, d_out, w2, k, nh, use_hash, (unsigned)drop_seed, w1t_frag, y, gate, (hipStream_t)stream);
 }

@@ -955,3 +955,63 @@ def test_heads1_wgrad_gen_equals_wgrad_of_the_materialised_hidden_gradient(geom,
     sw, sb = float(dw1[:, 44:300].abs().max()), float(db1.abs().max())
     assert float((dw1 - dw2).abs().max()) <= 2e-4 * sw, (float((dw1 - dw2).abs().max()), sw)
     assert float((db1 - db2).abs().max()) <= 2e-4 * sb, (float((db1 - db2).abs().max()), sb)
+
+
+def _heads1_dgrad_setup(L, dt, tdt, n, h, w, ks, seed0, drop):
+    nh = len(ks)
+    g = torch.Generator(device='cpu').manual_seed(seed0)
+    dout = torch.zeros(n, 8 * nh, h, w)
+    for i, k in enumerate(ks):
+        dout[:, 8 * i:8 * i + k] = torch.randn(n, k, h, w, generator=g)
+    w2 = [(torch.randn(k, 512, generator=g) * 0.05).to(tdt).float().cuda().contiguous() for k in ks]
+    w1 = [(torch.randn(512, 768, 1, 1, generator=g) * 0.03).cuda().contiguous() for _ in ks]      # conv5_1 weights [hidden][768 inputs]
+    gate = torch.randn(n, 256, h, w, generator=g)
+    fo, to, dv = framed(dout, 0, tdt)
+    fg, tg, gv = framed(gate, 1, tdt)
+    fd, td, dhv = framed(torch.zeros(n, 512 * nh, h, w), 1, tdt)
+    use_hash, seed = (1, 0xF00D) if drop == 'hash' else (0, 0)
+    karr = (C.c_int32 * nh)(*ks)
+    wp = (C.c_void_p * nh)(*[t.data_ptr() for t in w2])
+    check(L.dbx_head2_dgrad(dt, C.byref(dv), wp, karr, nh, C.byref(dhv), None, 512 * nh, use_hash, seed, stream_ptr()))
+    # W1^T restricted to input channels 512..767: rows = those 256 channels, K = the hidden channels of all heads, fragment order
+    d = ConvDesc(dt, 1, 1, 0, 512 * nh, 256, 0)
+    wimg = torch.zeros(L.dbx_conv_packed_elems(C.byref(d)) * _lib.ESIZE[dt], dtype=torch.uint8, device='cuda')
+    for i, wt in enumerate(w1):
+        check(L.dbx_pack_weight(dt, 5, ptr(wt), 512, 768, 1, 1, ptr(wimg), 256, 512 * nh, -512, 512 * i, stream_ptr()))
+    keep = (fo, fg, fd, w2, w1, wimg)
+    return keep, dv, gv, dhv, wp, karr, nh, use_hash, seed, wimg
+
+
+@pytest.mark.parametrize('dtn', ['f16', 'bf16'])
+@pytest.mark.parametrize('drop', ['hash', 'none'])
+@pytest.mark.parametrize('geom', [(3, 60, 60, [1, 4, 4, 8]), (2, 23, 37, [1, 4, 4, 8]), (5, 12, 30, [2, 4]), (1, 9, 11, [1])])
+def test_heads1_dgrad_gen_equals_the_gated_gemm_on_the_materialised_hidden_gradient(geom, drop, dtn):
+    """dbx_heads1_dgrad_gen (d_hid generated in registers as the GEMM's B operand) against dbx_head2_dgrad into memory + the ws / band 1x1
+    kernel with DBX_EPI_GATE on it.  W2 pre-rounded to the compute dtype: the two hidden gradients agree except for fp32 summation order,
+    the outputs to 16-bit rounding of sums in different orders; halo of the output untouched."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    n, h, w, ks = geom
+    keep, dv, gv, dhv, wp, karr, nh, use_hash, seed, wimg = _heads1_dgrad_setup(L, dt, tdt, n, h, w, ks, 17 + h, drop)
+    fy1, ty1, yv1 = framed(torch.zeros(n, 256, h, w), 1, tdt)
+    fy2, ty2, yv2 = framed(torch.zeros(n, 256, h, w), 1, tdt)
+    d = ConvDesc(dt, 1, 1, 0, 512 * nh, 256, _lib.EPI_GATE, 0)
+    plan = _lib.ConvPlan()
+    check(L.dbx_conv_plan(C.byref(d), C.byref(dhv), C.byref(yv1), C.byref(plan)))
+    if plan.w_frag:
+        d1 = ConvDesc(dt, 1, 1, 0, 512 * nh, 256, _lib.EPI_GATE | _lib.CONV_WFRAG, 0)
+        check(L.dbx_conv_forward(C.byref(d1), C.byref(dhv), ptr(wimg), None, C.byref(yv1), C.byref(gv), None, 0, stream_ptr()))
+    else:       # small problems: the row-major transposed image for the LDS kernels
+        w1 = keep[4]
+        wrow = torch.zeros(L.dbx_conv_packed_elems(C.byref(d)) * _lib.ESIZE[dt], dtype=torch.uint8, device='cuda')
+        for i, wt in enumerate(w1):
+            check(L.dbx_pack_weight(dt, 1, ptr(wt), 512, 768, 1, 1, ptr(wrow), 256, 512 * nh, -512, 512 * i, stream_ptr()))
+        check(L.dbx_conv_forward(C.byref(d), C.byref(dhv), ptr(wrow), None, C.byref(yv1), C.byref(gv), None, 0, stream_ptr()))
+    check(L.dbx_heads1_dgrad_gen(dt, C.byref(dv), wp, karr, nh, use_hash, seed, ptr(wimg), C.byref(yv2), C.byref(gv), stream_ptr()))
+    torch.cuda.synchronize()
+    a, b = ty1.float(), ty2.float()
+    assert float(a.abs().sum()) > 0
+    tol = (3e-3 if dtn == 'f16' else 2e-2) * float(a.abs().max())
+    assert float((a - b).abs().max()) <= tol, (float((a - b).abs().max()), float(a.abs().max()))
+    assert float(ty2[:, 0].float().abs().sum()) == 0 and float(ty2[:, :, 0].float().abs().sum()) == 0      # halo rows / columns untouched
+    assert torch.equal((b == 0), (a == 0)) or float(((b == 0) != (a == 0)).float().mean()) < 1e-3           # same gate pattern

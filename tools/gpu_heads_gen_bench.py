@@ -7,6 +7,7 @@ import torch
 
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')
+sys.path.insert(0, 'tools')
 from densebox_amd import _lib                                   # noqa: E402
 from densebox_amd._lib import check, ptr, stream_ptr            # noqa: E402
 from test_hip_kernels import framed, TDT                        # noqa: E402
@@ -48,9 +49,8 @@ def main():
     t_mat = timed(lambda: check(L.dbx_conv_wgrad_slice(dt, C.byref(dhv), C.byref(xv), 1, 1, 0, 512 * nh, 256, ptr(dw), 256, 0, ptr(db), ptr(sc), 0, stream_ptr())))
     t_gen = timed(lambda: check(L.dbx_heads1_wgrad_gen(dt, C.byref(dv), C.byref(xv), wp, karr, nh, use_hash, seed, 256, ptr(dw), 256, 0, ptr(db), ptr(sc), stream_ptr())))
     print('%s dW1 (2048 x 256 over %d pixels, incl. the split reduction): d_hid from memory %.1f us, generated %.1f us' % (dtn, n * h * w, t_mat, t_gen))
-    if hasattr(L, 'dbx_heads1_dgrad_gen'):
-        from gpu_heads_gen_dgrad import bench_dgrad              # noqa: E402
-        bench_dgrad(L, dt, tdt, dtn, dv, dhv, wp, karr, nh, use_hash, seed, n, h, w, timed)
+    from gpu_heads_gen_dgrad import bench_dgrad
+    bench_dgrad(L, dt, tdt, dtn, n, h, w, ks, timed)
 
 
 if __name__ == '__main__':
