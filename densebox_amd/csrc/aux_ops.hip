@@ -1163,7 +1163,7 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout, FrameGeo hid, FrameGeo dhid, FrameGeo dg, int nh, int slot,
                                                                    Head2Args ha, float* __restrict__ partial, float* __restrict__ bpartial,
                                                                    const unsigned char* __restrict__ mask, int mask_ld, int use_hash,
-                                                                   unsigned drop_seed, float sy, float sx, H2UPlan plan) {
+                                                                   unsigned drop_seed, float sy, float sx, H2UPlan plan, int nostore) {
     constexpr int V = 8, CS = 64, LPP = CS / V, D = H2U_D, PW = 32, NB = H2U_NB, NT = 6;
     static_assert(sizeof(T) == 2, "16-bit element types");
     __shared__ int s_x0[64], s_lo[32], s_hi[32];
@@ -1221,6 +1221,12 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
 #pragma unroll
     for (int i = 0; i < V; ++i) va[i] = vb[i] = 0.f;
     { int k; head2_load_w<V>(ha, hd, c0, active, w, k); }
+    if (nostore) {                                                      // the consumers generate d_hid with W2 in the compute dtype (GenHid): the same values here
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int i = 0; i < V; ++i) w[j][i] = to_f32(from_f32<T>(w[j][i]));
+    }
     // addresses = uniform row base (scalar registers) + a per-lane 32-bit element offset fixed for the whole walk (geo_pix per pixel is a
     // 64-bit vector multiply: quarter-rate instructions)
     auto row_of = [](const FrameGeo& g, int img, int y) { return ((size_t)(img * g.hp + y + g.pad) * g.wp) * (size_t)g.ld; };
@@ -1335,7 +1341,7 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
                     T* oe = (T*)&raw;
 #pragma unroll
                     for (int i = 0; i < V; ++i) oe[i] = from_f32<T>(o[i]);
-                    if (owner) *(u32x4*)((T*)dhid.base + row_of(dhid, n, oy) + lo_dhid) = raw;
+                    if (owner && !nostore) *(u32x4*)((T*)dhid.base + row_of(dhid, n, oy) + lo_dhid) = raw;
 #pragma unroll
                     for (int i = 0; i < V; ++i) { const float dv = to_f32(oe[i]); va[i] = fmaf(wa, dv, va[i]); vb[i] = fmaf(wb, dv, vb[i]); }
                 }
@@ -1432,12 +1438,15 @@ static int head2_backward_up_t(const dbx_view* dout, const dbx_view* hid, const 
     H2UPlan plan;
     bool fused = sizeof(T) == 2 && sy > 0.f && sy < 1.f && sx > 0.45f && sx < 1.f && hid->c % 64 == 0 && hid->h >= 2 && h2u_plan(hid->w, dg->w, sx, plan);
     if (const char* e = getenv("DBX_HEAD2_UP")) fused = fused && atoi(e) != 0;
+    const bool nostore = dhid->ptr == nullptr;                          // the hidden gradient is not wanted in memory (its consumers generate it)
+    DBX_REQUIRE(!nostore || (fused && !mask), "head2_backward_up without d_hid: needs the one-pass kernel (dbx_head2_backward_up_fused) and hash / no dropout");
     if (!fused) {                                                       // the two passes
         const int rc = head2_wgrad_t<T>(dout, hid, k, nh, dw, db, scratch, s, w2, dhid, mask, mask_ld, use_hash, drop_seed);
         return rc != DBX_OK ? rc : upsample_bwd_t<T>(dhid, dg, nullptr, s);
     }
     if constexpr (sizeof(T) == 2) {
-        VIEW_VEC_CHECK(T, hid, "head2_backward_up hid"); VIEW_VEC_CHECK(T, dhid, "head2_backward_up d_hid");
+        VIEW_VEC_CHECK(T, hid, "head2_backward_up hid");
+        if (!nostore) VIEW_VEC_CHECK(T, dhid, "head2_backward_up d_hid");
         DBX_REQUIRE(nh >= 1 && nh <= 4 && hid->c == 512 * nh && dout->c % nh == 0 && dout->c / nh >= 8, "head2_backward_up: nh in 1..4, hid of 512*nh channels, d_out of nh slots >= 8 channels");
         DBX_REQUIRE(dout->n == hid->n && dout->h == hid->h && dout->w == hid->w && dhid->n == hid->n && dhid->h == hid->h && dhid->w == hid->w && dhid->c == hid->c,
                     "head2_backward_up: shape mismatch");
@@ -1465,14 +1474,26 @@ static int head2_backward_up_t(const dbx_view* dout, const dbx_view* hid, const 
             DBX_HIP(hipFuncSetAttribute((const void*)head2_backward_up_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             attr_once.mark(attr_dev);
         }
-        hipLaunchKernelGGL(head2_backward_up_kernel<T>, dim3(blocks * nsl), dim3(256), smem, s, make_geo<T>(dout), make_geo<T>(hid), make_geo<T>(dhid),
-                           make_geo<T>(dg), nh, dout->c / nh, ha, partial, bpartial, mask, mask_ld, use_hash, drop_seed, sy, sx, plan);
+        hipLaunchKernelGGL(head2_backward_up_kernel<T>, dim3(blocks * nsl), dim3(256), smem, s, make_geo<T>(dout), make_geo<T>(hid), make_geo<T>(nostore ? hid : dhid),
+                           make_geo<T>(dg), nh, dout->c / nh, ha, partial, bpartial, mask, mask_ld, use_hash, drop_seed, sy, sx, plan, nostore ? 1 : 0);
         DBX_LAUNCH_CHECK();
         const int total = nh * 8 * 512 + nh * 8;
         hipLaunchKernelGGL(head2_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, s, partial, bpartial, blocks, nh, o);
         DBX_LAUNCH_CHECK();
     }
     return DBX_OK;
+}
+// 1 when dbx_head2_backward_up runs as ONE pass for these maps (the form that can leave d_hid out: d_hid->ptr == NULL)
+template <typename T> static int head2_up_fused_t(const dbx_view* hid, const dbx_view* dg) {
+    const float sy = ac_scale(dg->h, hid->h), sx = ac_scale(dg->w, hid->w);
+    H2UPlan plan;
+    bool fused = sizeof(T) == 2 && sy > 0.f && sy < 1.f && sx > 0.45f && sx < 1.f && hid->c % 64 == 0 && hid->h >= 2 && h2u_plan(hid->w, dg->w, sx, plan);
+    if (const char* e = getenv("DBX_HEAD2_UP")) fused = fused && atoi(e) != 0;
+    return fused ? 1 : 0;
+}
+extern "C" int dbx_head2_backward_up_fused(int32_t dtype, const dbx_view* hid, const dbx_view* d_g44) {
+    if (!hid || !d_g44) return 0;
+    switch (dtype) { case DBX_F16: return head2_up_fused_t<_Float16>(hid, d_g44); case DBX_BF16: return head2_up_fused_t<__bf16>(hid, d_g44); default: return 0; }
 }
 extern "C" int dbx_head2_backward_up(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const float* const* w2, const int32_t* k,
                                      int32_t nh, const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash,

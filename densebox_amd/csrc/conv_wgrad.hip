@@ -1945,6 +1945,14 @@ static int heads1_wgrad_gen_t(const dbx_view* d_out, const dbx_view* x, const fl
         return wgrad_t<T>(&dz, x, 1, 1, 0, 512 * nh, ci, dw, db, scratch, 0, s, ci_total, ci_off, &g);
     }
 }
+// 1 when dbx_heads1_wgrad_gen can run for x (the wide 1x1 kernel on a padded frame of >= 32 columns)
+extern "C" int dbx_heads1_wgrad_gen_ok(int32_t dtype, const dbx_view* x, int32_t nh) {
+    if (!x || (dtype != DBX_F16 && dtype != DBX_BF16) || nh < 1 || nh > 4 || x->pad < 1) return 0;
+    dbx_view dz = *x;
+    dz.c = dz.ld = 512 * nh; dz.c_off = 0;
+    const WgradPlan p = wgrad_plan(dtype, &dz, x, 1, 1);
+    return (p.wide2 && p.spi > 0) ? 1 : 0;
+}
 extern "C" int dbx_heads1_wgrad_gen(int32_t dtype, const dbx_view* d_out, const dbx_view* x, const float* const* w2, const int32_t* k, int32_t nh,
                                     int32_t use_hash, uint32_t drop_seed, int32_t ci, float* dw_oihw, int32_t dw_ci_total, int32_t dw_ci_off,
                                     float* db, void* scratch, void* stream) {

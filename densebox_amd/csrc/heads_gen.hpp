@@ -15,6 +15,9 @@
 // MFMAs + 2 generating ones, ~60 VALU instructions, 21 LDS reads, one barrier.  Persistent workgroups.
 #pragma once
 
+#ifndef HG_ABL
+#define HG_ABL 0                        // lab builds: 1 no generation in the loop, 2 no epilogue, 4 no main MFMAs, 8 no weight DMA
+#endif
 namespace hgen {
 constexpr int HB_BYTES = 16384, NST = 4, W2T_BYTES = 2048 * 16 + 64, LUT_BYTES = 256 * 16;
 constexpr int SMEM = NST * HB_BYTES + W2T_BYTES + LUT_BYTES;
@@ -119,31 +122,49 @@ __global__ __launch_bounds__(256, 1) void heads1_dgrad_gen_kernel(const HGenArgs
         for (int pf = 0; pf < 2; ++pf) dfr[pf] = (lh || !ok[pf]) ? (u32x4){0u, 0u, 0u, 0u} : dnx[pf];
     };
     u32x4 bfr[2][2][2];                                                 // [buffer][pixel fragment][K16 half]: generated B operands
-    auto gen = [&](int buf, int hb) {                                   // block hb of the current tile's pixels
-        const u32x4 wa = *(const u32x4*)(w2t + w2_base + (unsigned)hb * w2_step);
+    auto gen_w = [&](int hb) { return *(const u32x4*)(w2t + w2_base + (unsigned)hb * w2_step); };   // the generating MFMA's A operand
+    // Generation of block hb's operands in three pieces a block's schedule spreads out (below): (1) both generating MFMAs -- inline asm
+    // with VGPR destinations and a zero C operand: all 256 AGPRs hold the accumulators, and the builtin's result landed in AGPRs too,
+    // the compiler parked 16 accumulator registers in VGPRs around every block (80 register moves per block and wave); (2) the two hashes
+    // and the four table reads, independent of the MFMAs' results; (3) behind s_nops covering the MFMA-write -> VALU-read hazard the
+    // assembler does not see for asm operands: packing to 16-bit pairs and masking.
+    f32x16 dd[2];
+    u32x4 mk[2][2];
+    auto gen_mma = [&](const u32x4& wa) {
+        if constexpr (DType<T>::id == DBX_F16)
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_f16 %1, %2, %4, 0"
+                         : "=&v"(dd[0]), "=&v"(dd[1]) : "v"(wa), "v"(dfr[0]), "v"(dfr[1]));
+        else
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, 0"
+                         : "=&v"(dd[0]), "=&v"(dd[1]) : "v"(wa), "v"(dfr[0]), "v"(dfr[1]));
+    };
+    auto gen_masks = [&](int hb) {
         const unsigned cc = a.g.seed ^ ((unsigned)hb * 0x85EBCA77u);
 #pragma unroll
         for (int pf = 0; pf < 2; ++pf) {
-            f32x16 d;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) d[r] = 0.f;
-            Mma32<T>::run(wa, dfr[pf], d);
             unsigned x = cc ^ hm[pf];
             x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
             const unsigned bits = (x >> (8 * lh)) | nodrop;             // bit 16 t + e: hidden channel 16 t + 8 lh + e of the block
 #pragma unroll
+            for (int t = 0; t < 2; ++t) mk[pf][t] = *(const u32x4*)(lut + ((bits >> (16 * t)) & 255u) * 16);
+        }
+    };
+    auto gen_pack = [&](int buf) {
+        asm volatile("s_nop 15\n\ts_nop 4" : "+v"(dd[0]), "+v"(dd[1]));
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const u32x4 mk = *(const u32x4*)(lut + ((bits >> (16 * t)) & 255u) * 16);
                 typedef float f32x2v __attribute__((ext_vector_type(2)));
                 typedef T t2v __attribute__((ext_vector_type(2)));
                 u32x4 o;
 #pragma unroll
                 for (int p = 0; p < 4; ++p)
-                    o[p] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v){d[8 * t + 2 * p], d[8 * t + 2 * p + 1]}, t2v)) & mk[p];
+                    o[p] = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v){dd[pf][8 * t + 2 * p], dd[pf][8 * t + 2 * p + 1]}, t2v)) & mk[pf][t][p];
                 bfr[buf][pf][t] = o;
             }
-        }
     };
+    auto gen = [&](int buf, int hb, const u32x4& wa) { gen_mma(wa); gen_masks(hb); gen_pack(buf); };
 
     f32x16 acc[2][8];
 #pragma unroll
@@ -160,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void heads1_dgrad_gen_kernel(const HGenArgs
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(dnx[0]), "+v"(dnx[1]) :: "memory");
     __syncthreads();                                                    // tables written, blocks 0..2 landed
     dswap();
-    gen(0, 0);
+    gen(0, 0, gen_w(0));
 
     int st = 0;                                                         // stage of the current block
     for (;;) {
@@ -173,10 +194,18 @@ __global__ __launch_bounds__(256, 1) void heads1_dgrad_gen_kernel(const HGenArgs
                 // covers the other waves'), every wave is past block h - 1's stage
                 asm volatile("s_waitcnt vmcnt(8)" : "+v"(dnx[0]), "+v"(dnx[1]) :: "memory");
                 __builtin_amdgcn_s_barrier();
-                issue();                                                // block h + 3 into the stage block h - 1 left
+                // schedule of a block: the eight weight fragments of the first K = 16 half are requested right behind the barrier and land
+                // under the generation of the NEXT block's operands (its table reads, two MFMAs, ~60 VALU instructions); each of them is
+                // then used for two MFMAs while the matching fragment of the second half is read
                 const char* S = smem + st * HB_BYTES + lane * 16;
-                // the next block's operands: the next head's (or the next tile's first head's) d_out slots arrive three blocks ahead
                 const bool last = h + 1 == nhb;
+                const u32x4 wa = gen_w(last ? 0 : h + 1);               // (first: the generating MFMAs wait for this read only)
+                u32x4 wf0[8], wf1[8];
+#pragma unroll
+                for (int cf = 0; cf < 8; ++cf) wf0[cf] = *(const u32x4*)(S + cf * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(HG_ABL & 8)) issue();                             // block h + 3 into the stage block h - 1 left
+                // the next block's operands: the next head's (or the next tile's first head's) d_out slots arrive three blocks ahead
                 if ((h & 15) == 12) {                                   // (uniform)
                     const bool wrap = h + 4 >= nhb;
                     dfetch(wrap ? tile + stride : tile, wrap ? 0 : (h + 4) >> 4);
@@ -185,52 +214,76 @@ __global__ __launch_bounds__(256, 1) void heads1_dgrad_gen_kernel(const HGenArgs
                     if (last) set_tile(tile + stride);                  // (past the last tile: clamped pixels, results unused)
                     dswap();
                 }
-                gen(par ^ 1, last ? 0 : h + 1);
+                if (!(HG_ABL & 1)) { gen_mma(wa); gen_masks(last ? 0 : h + 1); }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                for (int cf = 0; cf < 8; ++cf) {
+                    wf1[cf] = *(const u32x4*)(S + (8 + cf) * 1024);
+                    if (HG_ABL & 4) continue;
+                    Mma32<T>::run(wf0[cf], bfr[par][0][0], acc[0][cf]);
+                    Mma32<T>::run(wf0[cf], bfr[par][1][0], acc[1][cf]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // second half: 16 MFMAs with the next block's packing and masking (32 VALU instructions) between them
+                if (!(HG_ABL & 1)) gen_pack(par ^ 1);
 #pragma unroll
-                    for (int cf = 0; cf < 8; ++cf) {
-                        const u32x4 wf = *(const u32x4*)(S + (t * 8 + cf) * 1024);
-                        Mma32<T>::run(wf, bfr[par][0][t], acc[0][cf]);
-                        Mma32<T>::run(wf, bfr[par][1][t], acc[1][cf]);
-                    }
+                for (int cf = 0; cf < 8; ++cf) {
+                    if (HG_ABL & 4) continue;
+                    Mma32<T>::run(wf1[cf], bfr[par][0][1], acc[0][cf]);
+                    Mma32<T>::run(wf1[cf], bfr[par][1][1], acc[1][cf]);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                }
                 st = (st + 1) & 3;
             }
         }
-        // ---- epilogue of the tile (set_tile has already moved m / ok to the next tile: recompute this tile's pixels)
+        // ---- epilogue of the tile (set_tile has already moved m / ok to the next tile: recompute this tile's pixels).  All 32 gate chunks
+        // of the wave's two pixel fragments are requested up front: a load consumed right behind its issue exposes a memory latency 32 times
+        // per tile with one wave per SIMD (the first version: a third of the tile's time)
         __builtin_amdgcn_sched_barrier(0);
+        if (!(HG_ABL & 2)) {
+            T* ypix[2];
+            bool okp[2];
+            u32x4 gt[2][8][2];
 #pragma unroll
-        for (int pf = 0; pf < 2; ++pf) {
-            const int mm = tile * 256 + wave * 64 + pf * 32 + l31;
-            const bool okp = mm < a.npix;
-            const int mc = okp ? mm : 0;
-            const int hw = a.g.H * a.g.W;
-            const int n = mc / hw, rem = mc - n * hw, oy = rem / a.g.W, ox = rem - oy * a.g.W;
-            T* ypix = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (size_t)a.y_ld + 8 * lh;
-            const T* gpix = (const T*)a.gate + (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld + 8 * lh;
+            for (int pf = 0; pf < 2; ++pf) {
+                const int mm = tile * 256 + wave * 64 + pf * 32 + l31;
+                okp[pf] = mm < a.npix;
+                const int mc = okp[pf] ? mm : 0;
+                const int hw = a.g.H * a.g.W;
+                const int n = mc / hw, rem = mc - n * hw, oy = rem / a.g.W, ox = rem - oy * a.g.W;
+                ypix[pf] = (T*)a.y + (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (size_t)a.y_ld + 8 * lh;
+                const T* gpix = (const T*)a.gate + (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld + 8 * lh;
 #pragma unroll
-            for (int cf = 0; cf < 8; ++cf) {
+                for (int cf = 0; cf < 8; ++cf)
 #pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    u32x2 pk[2];
+                    for (int jp = 0; jp < 2; ++jp) gt[pf][cf][jp] = *(const u32x4*)(gpix + cf * 32 + 16 * jp);
+            }
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const int j = 2 * jp + jj;
-                        T p4[4] = {from_f32<T>(acc[pf][cf][4 * j]), from_f32<T>(acc[pf][cf][4 * j + 1]), from_f32<T>(acc[pf][cf][4 * j + 2]),
-                                   from_f32<T>(acc[pf][cf][4 * j + 3])};
-                        pk[jj] = *(const u32x2*)p4;
+            for (int pf = 0; pf < 2; ++pf) {
+#pragma unroll
+                for (int cf = 0; cf < 8; ++cf) {
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        u32x2 pk[2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = 2 * jp + jj;
+                            T p4[4] = {from_f32<T>(acc[pf][cf][4 * j]), from_f32<T>(acc[pf][cf][4 * j + 1]), from_f32<T>(acc[pf][cf][4 * j + 2]),
+                                       from_f32<T>(acc[pf][cf][4 * j + 3])};
+                            pk[jj] = *(const u32x2*)p4;
+                        }
+                        // lower half keeps its group 2 jp and receives the upper half's; upper half receives the lower's 2 jp + 1: 8 consecutive channels per lane
+                        const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
+                        const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
+                        const u32x4 o = gate_packed16((u32x4){r0[0], r1[0], r0[1], r1[1]}, gt[pf][cf][jp]);
+                        if (okp[pf]) *(u32x4*)(ypix[pf] + cf * 32 + 16 * jp) = o;
                     }
-                    // lower half keeps its group 2 jp and receives the upper half's; upper half receives the lower's 2 jp + 1: 8 consecutive channels per lane
-                    const auto r0 = __builtin_amdgcn_permlane32_swap(pk[0].x, pk[1].x, false, false);
-                    const auto r1 = __builtin_amdgcn_permlane32_swap(pk[0].y, pk[1].y, false, false);
-                    u32x4 o = (u32x4){r0[0], r1[0], r0[1], r1[1]};
-                    if (okp) {
-                        o = gate_packed16(o, *(const u32x4*)(gpix + cf * 32 + 16 * jp));
-                        *(u32x4*)(ypix + cf * 32 + 16 * jp) = o;
-                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[pf][cf][r] = 0.f;
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[pf][cf][r] = 0.f;
             }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -69,12 +69,12 @@ class Plan:
     @staticmethod
     def env_flags():
         """The environment switches that decide which buffers a plan holds (part of the plan cache key)."""
-        return tuple(os.environ.get(k, '1') != '0' for k in ('DBX_LIN_BWD', 'DBX_REFINE_LINEAR', 'DBX_POOL_IDX'))
+        return tuple(os.environ.get(k, '1') != '0' for k in ('DBX_LIN_BWD', 'DBX_REFINE_LINEAR', 'DBX_POOL_IDX', 'DBX_HEADS_GEN'))
 
     def __init__(self, kind, n, h, w, dtype_id, device, train):
         self.kind, self.n, self.h, self.w, self.dtype_id, self.train = kind, n, h, w, dtype_id, train
         self.flags = Plan.env_flags()
-        lin_bwd, lin_refine, use_idx = self.flags
+        lin_bwd, lin_refine, use_idx, heads_gen = self.flags
         lin_bwd = lin_bwd and dtype_id != _lib.F32
         es = _lib.ESIZE[dtype_id]
         self.cin0 = 16 // es                      # conv1_1 input channels padded to one 16-byte chunk
@@ -124,9 +124,17 @@ class Plan:
             if not lin_bwd:
                 add('d_ups', h4, w4, 512, pad=0)          # (the heads' backward by linearity never forms it)
             add('d_p1', h2, w2, 64, pad=0); add('d_p2', h4, w4, 128, pad=0); add('d_p3', h8, w8, 256, pad=0)
-            add('d_hid', h4, w4, 512 * nh, pad=1)         # congruent with 'fusion'
             add('d_g44', h8, w8, 512 * nh, pad=1)         # up^T(d_hid): the hidden gradient on conv4_4's grid, congruent with 'a44'
             add('d_out', h4, w4, self.crf * nh, pad=0)    # dL/d(head outputs), one crf-channel slot per head
+            # The hidden gradient itself (944 MB at batch 64) is not held when its consumers GENERATE it (dbx_heads1_wgrad_gen /
+            # dbx_heads1_dgrad_gen / dbx_head2_backward_up without a d_hid: round 4; DBX_HEADS_GEN=0 keeps it in memory).  A backward that
+            # cannot use them (an injected dropout mask, a side stream) gets the buffer on demand (Engine._d_hid).
+            L = _lib.lib()
+            self.heads_gen = bool(heads_gen and lin_bwd and
+                                  L.dbx_head2_backward_up_fused(dtype_id, C.byref(B['hid'].view()), C.byref(B['d_g44'].view())) and
+                                  L.dbx_heads1_wgrad_gen_ok(dtype_id, C.byref(B['fusion'].view(512, 256)), nh))
+            if not self.heads_gen:
+                add('d_hid', h4, w4, 512 * nh, pad=1)     # congruent with 'fusion'
             if rf_convs:
                 add('d_rfo', h4, w4, self.crf, pad=0)
                 add('d_rf_u', h4, w4, 64, pad=0)
@@ -140,6 +148,8 @@ class Plan:
             b.off = off
             off += _align(b.bytes) + b.guard
         self.total = off
+        if not train:
+            self.heads_gen = False
         self.drop_active = self.drop_hash = False
         self.frag = {}             # (stem, 'f' | 'b') -> fragment-order weights? (Engine._frag)
         self.drop_seed = 0
@@ -330,6 +340,8 @@ class Engine:
                 r = self.conv_plan(dt, B['fusion'].view(), B['hid'].view(), 1, 1, 0, 768, 512 * nh, _lib.EPI_BIAS | _lib.EPI_DROPHASH)[2]
             elif which == 'ba' and 'd_g44' in B and dt != _lib.F32:
                 r = self.conv_plan(dt, B['d_g44'].view(), B['d_a44'].view(), 1, 1, 0, 512 * nh, 512, _lib.EPI_GATE)[2]
+            elif which == 'bc' and getattr(P, 'heads_gen', False):
+                r = True                                   # dbx_heads1_dgrad_gen takes the fragment-order image
             elif which == 'bc' and 'd_hid' in B and dt != _lib.F32:
                 r = self.conv_plan(dt, B['d_hid'].view(), B['d_c34'].view(), 1, 1, 0, 512 * nh, 256, _lib.EPI_GATE)[2]
             elif which in ('ba', 'bc'):
@@ -816,7 +828,19 @@ class Engine:
         after ONE transposed up-sampling of the hidden gradient.  DBX_LIN_BWD=0 keeps the full-resolution GEMMs."""
         return dt != _lib.F32 and os.environ.get('DBX_LIN_BWD', '1') != '0'
 
-    def _wgrad(self, dt, dz, x, kh, kw, cpad, co, ci, dw, db, accumulate=0, ci_total=None, ci_off=0):
+    def _d_hid(self, P):
+        """The hidden-gradient buffer; plans whose heads backward generates it hold none: made on first use (injected masks, side streams)."""
+        b = P.B.get('d_hid')
+        if b is None:
+            hb = P.B['hid']
+            b = Buf('d_hid', hb.n, hb.h, hb.w, hb.c, 1, hb.dtype_id)
+            P._d_hid_store = torch.zeros(2 * b.guard + _align(b.bytes) + 256, dtype=torch.uint8, device=P.ws.device)
+            b.base = _align(P._d_hid_store.data_ptr() + b.guard)
+            P.B['d_hid'] = b
+        return b
+
+    def _wgrad(self, dt, dz, x, kh, kw, cpad, co, ci, dw, db, accumulate=0, ci_total=None, ci_off=0, gen=None):
+        """gen = (d_out view, w2 pointers, ks, nh, use_hash, seed): dz is the heads' hidden gradient, generated in the kernel (dz: shape only)."""
         need = self.L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dz), C.byref(x), kh, kw)
         if getattr(self, '_wg_scratch', None) is None or self._wg_scratch.numel() < need:
             self._wg_scratch = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=dw.device)
@@ -824,7 +848,11 @@ class Engine:
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if ci_total is None:
+        if gen is not None:
+            dov, w2p, ks, nh, use_hash, seed = gen
+            check(self.L.dbx_heads1_wgrad_gen(dt, C.byref(dov), C.byref(x), w2p, ks, nh, use_hash, seed, ci, ptr(dw), ci_total, ci_off, ptr(db),
+                                              ptr(self._wg_scratch), stream_ptr()))
+        elif ci_total is None:
             check(self.L.dbx_conv_wgrad(dt, C.byref(dz), C.byref(x), kh, kw, cpad, co, ci, ptr(dw), ptr(db),
                                         ptr(self._wg_scratch), accumulate, stream_ptr()))
         else:
@@ -835,6 +863,8 @@ class Engine:
             buf = C.create_string_buffer(64)                      # the library's own choice (dbx_conv_wgrad_plan)
             check(self.L.dbx_conv_wgrad_plan(dt, C.byref(dz), C.byref(x), kh, kw, buf, 64, None))
             name = buf.value.decode()
+            if gen is not None:
+                name = name.replace('>', ',gen>')
             prof.append({'kernel': name, 'flops': 2.0 * dz.n * dz.h * dz.w * kh * kw * ci * co, 'start': ev0, 'end': ev1})
 
     def backward_raw(self, grad_outs):
@@ -979,6 +1009,14 @@ class Engine:
         hash_on, hash_seed = (1 if P.drop_hash else 0), (P.drop_seed if P.drop_hash else 0)
         lin = self._lin_bwd(dt)
         up_done = False
+        # the hidden gradient d_hid = keep * (d_out W2): generated inside its two 60x60 consumers (no 944 MB map written and read twice) when
+        # the plan holds no buffer for it and nothing needs it in memory (an injected dropout mask, the side-stream schedule do)
+        gen = bool(getattr(P, 'heads_gen', False) and lin and side is None and mask_p is None)
+        if gen:
+            dhid_v = View(None, hv.n, hv.h, hv.w, 1, 512 * nh, 0, 512 * nh)     # "not in memory" for dbx_head2_backward_up
+        else:
+            dhid_v = self._d_hid(P).view()
+        w2p = (C.c_void_p * nh)(*[w.data_ptr() for w in w2s])
         if side is not None:
             def run_h2():
                 check(L.dbx_head2_wgrad(dt, C.byref(B['d_out'].view()), C.byref(hv), ks, nh,
@@ -988,16 +1026,16 @@ class Engine:
                     sink.ready(h2_names)
             on_side(run_h2)
             check(L.dbx_head2_dgrad(dt, C.byref(B['d_out'].view()), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]), ks, nh,
-                                    C.byref(B['d_hid'].view()), mask_p, 512 * nh, hash_on, hash_seed, s))
+                                    C.byref(dhid_v), mask_p, 512 * nh, hash_on, hash_seed, s))
         elif lin:   # one pass over the pixels, and the hidden gradient goes to conv4_4's grid (d_g44 = up^T(d_hid)) while it is in registers
             check(L.dbx_head2_backward_up(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]), ks, nh,
-                                          C.byref(B['d_hid'].view()), mask_p, 512 * nh, hash_on, hash_seed,
+                                          C.byref(dhid_v), mask_p, 512 * nh, hash_on, hash_seed,
                                           (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
                                           ptr(self._h2_scratch), C.byref(B['d_g44'].view()), s))
             up_done = True
         else:       # one pass over the pixels: the d_hid write overlaps the hid read
             check(L.dbx_head2_backward(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]), ks, nh,
-                                       C.byref(B['d_hid'].view()), mask_p, 512 * nh, hash_on, hash_seed,
+                                       C.byref(dhid_v), mask_p, 512 * nh, hash_on, hash_seed,
                                        (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
                                        ptr(self._h2_scratch), s))
             if sink is not None:
@@ -1016,14 +1054,18 @@ class Engine:
         c34 = B['fusion'].view(512, 256)
         if lin and not up_done:
             # the hidden gradient on conv4_4's grid: d_g44 = up^T(d_hid) (one HBM-bound pass over the 2048-channel map)
-            check(L.dbx_upsample_bilinear_bwd(dt, C.byref(B['d_hid'].view()), C.byref(B['d_g44'].view()), None, s))
+            check(L.dbx_upsample_bilinear_bwd(dt, C.byref(dhid_v), C.byref(B['d_g44'].view()), None, s))
 
         def run_h1():
             if lin:       # columns 0..511 of dW1 from (d_g44, a44) at 30x30, columns 512..767 (+ the bias) from (d_hid, c34) at 60x60
                 self._wgrad(dt, B['d_g44'].view(), B['a44'].view(), 1, 1, 0, 512 * nh, 512, dw1, None, ci_total=768, ci_off=0)
-                self._wgrad(dt, B['d_hid'].view(), c34, 1, 1, 0, 512 * nh, 256, dw1, db1, ci_total=768, ci_off=512)
+                if gen:
+                    self._wgrad(dt, dhid_v, c34, 1, 1, 0, 512 * nh, 256, dw1, db1, ci_total=768, ci_off=512,
+                                gen=(B['d_out'].view(), w2p, ks, nh, hash_on, hash_seed))
+                else:
+                    self._wgrad(dt, dhid_v, c34, 1, 1, 0, 512 * nh, 256, dw1, db1, ci_total=768, ci_off=512)
             else:
-                self._wgrad(dt, B['d_hid'].view(), B['fusion'].view(), 1, 1, 0, 512 * nh, 768, dw1, db1)
+                self._wgrad(dt, dhid_v, B['fusion'].view(), 1, 1, 0, 512 * nh, 768, dw1, db1)
             if sink is not None:
                 sink.ready(w1n + b1n)
         on_side(run_h1)
@@ -1036,8 +1078,21 @@ class Engine:
             fa, fc = self._frag_heads(P, dt, 'ba'), self._frag_heads(P, dt, 'bc')
             self._conv(dt, B['d_g44'].view(), B['d_a44'].view(), self._w_heads1_bwd_part(dt, 'a', frag=fa), None, 1, 1, 0, 512 * nh, 512,
                        _lib.EPI_GATE | (_lib.CONV_WFRAG if fa else 0), gate=B['a44'].view())
-            self._conv(dt, B['d_hid'].view(), B['d_c34'].view(), self._w_heads1_bwd_part(dt, 'c', frag=fc), None, 1, 1, 0, 512 * nh, 256,
-                       _lib.EPI_GATE | (_lib.CONV_WFRAG if fc else 0), gate=c34)
+            if gen:
+                if prof is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                check(L.dbx_heads1_dgrad_gen(dt, C.byref(B['d_out'].view()), w2p, ks, nh, hash_on, hash_seed,
+                                             ptr(self._w_heads1_bwd_part(dt, 'c', frag=True)), C.byref(B['d_c34'].view()), C.byref(c34), s))
+                if prof is not None:
+                    ev1.record()
+                    prof.append({'kernel': 'heads1_dgrad_gen_kernel<%s>' % ('f16', 'bf16', 'f32')[dt],
+                                 'flops': 2.0 * hv.n * hv.h * hv.w * 512 * nh * (256 + 8), 'start': ev0, 'end': ev1})
+            else:
+                if fc and getattr(P, 'heads_gen', False):      # (the plan chose the fragment image for the generating kernel: does this GEMM take it?)
+                    fc = self.conv_plan(dt, dhid_v, B['d_c34'].view(), 1, 1, 0, 512 * nh, 256, _lib.EPI_GATE)[2]
+                self._conv(dt, dhid_v, B['d_c34'].view(), self._w_heads1_bwd_part(dt, 'c', frag=fc), None, 1, 1, 0, 512 * nh, 256,
+                           _lib.EPI_GATE | (_lib.CONV_WFRAG if fc else 0), gate=c34)
         elif dt != _lib.F32:
             bfrag = self._frag_heads(P, dt, 'b')
             w1t = self._w_heads1_bwd(dt, frag=bfrag)              # [768 rows][512*nh] (or its fragment-order image)
@@ -1047,11 +1102,11 @@ class Engine:
             if prof is not None:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            check(L.dbx_conv_forward_split(C.byref(d), C.byref(B['d_hid'].view()), ptr(w1t), None, C.byref(B['d_ups'].view()), None,
+            check(L.dbx_conv_forward_split(C.byref(d), C.byref(dhid_v), ptr(w1t), None, C.byref(B['d_ups'].view()), None,
                                            C.byref(B['d_c34'].view()), C.byref(c34), 512, _lib.EPI_GATE, s))
             if prof is not None:
                 ev1.record()
-                hv = B['d_hid'].view()
+                hv = dhid_v
                 dv = B['d_ups'].view()
                 both = View(dv.ptr, dv.n, dv.h, dv.w, dv.pad, 768, 0, 768)
                 prof.append({'kernel': self.conv_plan(dt, hv, both, 1, 1, 0, 512 * nh, 768, 0)[1] if bfrag else
@@ -1059,8 +1114,8 @@ class Engine:
                              'flops': 2.0 * hv.n * hv.h * hv.w * 512 * nh * 768, 'start': ev0, 'end': ev1})
         else:
             w1t = self._w_heads1_bwd(dt, frag=False)
-            self._conv(dt, B['d_hid'].view(), B['d_ups'].view(), w1t, None, 1, 1, 0, 512 * nh, 512, 0)
-            self._conv(dt, B['d_hid'].view(), B['d_c34'].view(), w1t[512 * row_bytes:], None, 1, 1, 0, 512 * nh, 256,
+            self._conv(dt, dhid_v, B['d_ups'].view(), w1t, None, 1, 1, 0, 512 * nh, 512, 0)
+            self._conv(dt, dhid_v, B['d_c34'].view(), w1t[512 * row_bytes:], None, 1, 1, 0, 512 * nh, 256,
                        _lib.EPI_GATE, gate=c34)
         if not lin:
             check(L.dbx_upsample_bilinear_bwd(dt, C.byref(B['d_ups'].view()), C.byref(B['d_a44'].view()),

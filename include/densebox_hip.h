@@ -41,7 +41,7 @@ const char* dbx_last_error(void);
  *   2  (round 3) dbx_loss_forward_backward's scratch grew from n doubles to dbx_loss_scratch_bytes(n) (mask planes + partial sums);
  *      the dbx_pack_multi job record's former pad field became rows_lim
  *   3  (round 4) fused entry points added (see the round-4 section below); nothing removed */
-#define DBX_ABI_VERSION 3
+#define DBX_ABI_VERSION 4
 int dbx_version(void);
 /* device sanity: returns gfx arch number (950) of `device`, or <0 */
 int dbx_device_arch(int device);
@@ -188,6 +188,23 @@ int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const dbx_view* hid
 int dbx_head2_backward_up(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const float* const* w2, const int32_t* k,
                           int32_t nh, const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash,
                           uint32_t drop_seed, float* const* dw, float* const* db, void* scratch, const dbx_view* d_g44, void* stream);
+/* Round 4: the hidden gradient need not exist in memory.  d_hid = keep * scale * (d_out W2) has <= 8 input channels per head, so
+ * its consumers GENERATE it, 32 channels x 32 pixels per MFMA (W2 and d_out in the compute dtype, keep bits from the forward's hash):
+ *   dbx_head2_backward_up with d_hid->ptr == NULL (the view's shape still describes the map) does not store it (one-pass form
+ *     only: dbx_head2_backward_up_fused() == 1; hash dropout or none; it rounds W2 to the compute dtype like the generators),
+ *   dbx_heads1_wgrad_gen = dbx_conv_wgrad_slice(d_hid, x, 1x1, ...) (x on a padded frame of >= 32 columns: dbx_heads1_wgrad_gen_ok()),
+ *   dbx_heads1_dgrad_gen = dbx_conv_forward(d_hid, W1^T, DBX_EPI_GATE) -> y (256 channels; w1t_frag = dbx_pack_weight mode 5 image,
+ *     rows_pad 256, cin_pad 512 nh).
+ * d_out: the compact [N, H, W] map (pad 0) with one slot of >= 8 channels per head, channels >= k[i] zero; w2[i]: fp32 [k[i]][512].
+ * Results equal the in-memory forms up to fp32 summation order (W2 representable in the compute dtype) / its rounding (otherwise).
+ * (Heads: DenseBox.py:158-162, :174-178; their backward is autograd's in the reference.) */
+int dbx_head2_backward_up_fused(int32_t dtype, const dbx_view* hid, const dbx_view* d_g44);
+int dbx_heads1_wgrad_gen_ok(int32_t dtype, const dbx_view* x, int32_t nh);
+int dbx_heads1_wgrad_gen(int32_t dtype, const dbx_view* d_out, const dbx_view* x, const float* const* w2, const int32_t* k, int32_t nh,
+                         int32_t use_hash, uint32_t drop_seed, int32_t ci, float* dw_oihw, int32_t dw_ci_total, int32_t dw_ci_off,
+                         float* db, void* scratch, void* stream);
+int dbx_heads1_dgrad_gen(int32_t dtype, const dbx_view* d_out, const float* const* w2, const int32_t* k, int32_t nh, int32_t use_hash,
+                         uint32_t drop_seed, const void* w1t_frag, const dbx_view* y, const dbx_view* gate, void* stream);
 
 /* eval-mode folding of one head, Conv1x1(768->512) -> Dropout(identity) -> Conv1x1(512->k), into a single 768->k map
  * (no non-linearity in between, DenseBox.py:158-162): w_out[k][768] = w2 w1, b_out[k] = w2 b1 + b2 (all fp32) */
