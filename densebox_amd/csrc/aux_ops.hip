@@ -1042,7 +1042,10 @@ __global__ __launch_bounds__(512) void head2_wgrad_kernel(FrameGeo dout, FrameGe
         bpartial[(size_t)blockIdx.x * 32 + hh * 8 + j] = o;
     }
 }
-struct Head2Out { float* dw[4]; float* db[4]; int k[4]; };
+struct Head2Out { float* dw[4]; float* db[4]; int k[4];
+                  // where head hd's partial blocks are: the launch that produced them wrote [blk][nhl][8][512] floats at poff (+ [blk][32] bias
+                  // sums at boff), head hd is its local head hl; nblk[hd] blocks (one launch for all heads: poff 0, nhl = nh, hl = hd)
+                  long long poff[4], boff[4]; int nblk[4], nhl[4], hl[4]; };
 // 64 consecutive (head, j, c) elements per workgroup; wave w of 16 sums partial blocks w, w+16, ... (four loads in flight),
 // the 16 wave sums are added in a fixed order.
 __global__ __launch_bounds__(1024) void head2_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bpartial, int nblk,
@@ -1050,18 +1053,22 @@ __global__ __launch_bounds__(1024) void head2_wgrad_reduce_kernel(const float* _
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int ne = nh * 8 * 512, e = blockIdx.x * 64 + lane;
-    const size_t stride = (size_t)nh * 4096;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (e < ne) {
+    if (e < ne) {                                                       // (a workgroup's 64 elements belong to one head)
+        const int hd = e / 4096;
+        const size_t stride = (size_t)o.nhl[hd] * 4096;
+        const float* pp = partial + o.poff[hd] + (size_t)o.hl[hd] * 4096 + (e - hd * 4096);
+        const int nb = o.nblk[hd];
         int b = w;
-        for (; b + 48 < nblk; b += 64) {
-            s0 += partial[(size_t)b * stride + e]; s1 += partial[(size_t)(b + 16) * stride + e];
-            s2 += partial[(size_t)(b + 32) * stride + e]; s3 += partial[(size_t)(b + 48) * stride + e];
+        for (; b + 48 < nb; b += 64) {
+            s0 += pp[(size_t)b * stride]; s1 += pp[(size_t)(b + 16) * stride];
+            s2 += pp[(size_t)(b + 32) * stride]; s3 += pp[(size_t)(b + 48) * stride];
         }
-        for (; b < nblk; b += 16) s0 += partial[(size_t)b * stride + e];
+        for (; b < nb; b += 16) s0 += pp[(size_t)b * stride];
     } else if (e < ne + nh * 8) {
-        const int q = e - ne;
-        for (int b = w; b < nblk; b += 16) s0 += bpartial[(size_t)b * 32 + (q / 8) * 8 + (q % 8)];
+        const int q = e - ne, hd = q / 8;
+        const float* bp = bpartial + o.boff[hd] + o.hl[hd] * 8 + (q % 8);
+        for (int b = w; b < o.nblk[hd]; b += 16) s0 += bp[(size_t)b * 32];
     }
     red[w][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -1114,6 +1121,7 @@ static int head2_wgrad_t(const dbx_view* dout, const dbx_view* hid, const int32_
         hipLaunchKernelGGL((head2_wgrad_kernel<T, false>), dim3(blocks), dim3(threads), 0, s, make_geo<T>(dout), make_geo<T>(hid), nh, dout->c / nh,
                            partial, bpartial, ha, make_geo<T>(hid), (const unsigned char*)nullptr, 0, 0, 0u);
     DBX_LAUNCH_CHECK();
+    for (int i = 0; i < 4; ++i) { o.poff[i] = 0; o.boff[i] = 0; o.nblk[i] = blocks; o.nhl[i] = nh; o.hl[i] = i; }
     const int total = nh * 8 * 512 + nh * 8;
     hipLaunchKernelGGL(head2_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, s, partial, bpartial, blocks, nh, o);
     DBX_LAUNCH_CHECK();
@@ -1159,8 +1167,11 @@ extern "C" int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const db
 #endif
 struct H2UHalf { int px_lo, px_n, own_lo, own_hi, ix_lo, ix_n; };      // pixel columns walked / owned [own_lo, own_hi), source columns reduced
 struct H2UPlan { int halves; H2UHalf h[2]; };
-template <typename T>
-__global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout, FrameGeo hid, FrameGeo dhid, FrameGeo dg, int nh, int slot,
+// KJ: the d_out channels multiplied out (the launch's heads have k <= KJ: one launch per run of heads with the same rounded-up k --
+// one loop body per kernel, unlike the per-k copies inside one kernel that overflowed the instruction cache); hd0 / nhl: the launch's
+// first head and head count (its hidden channels are hid's [512 hd0, 512 (hd0 + nhl)), its partial blocks [blk][nhl][8][512]).
+template <typename T, int KJ>
+__global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout, FrameGeo hid, FrameGeo dhid, FrameGeo dg, int hd0, int nhl, int slot,
                                                                    Head2Args ha, float* __restrict__ partial, float* __restrict__ bpartial,
                                                                    const unsigned char* __restrict__ mask, int mask_ld, int use_hash,
                                                                    unsigned drop_seed, float sy, float sx, H2UPlan plan, int nostore) {
@@ -1170,12 +1181,12 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
     __shared__ float s_l0[64], s_l1[64];
     extern __shared__ __attribute__((aligned(16))) char h2u_smem[];
     float* const s_v = (float*)h2u_smem;                                // ring of 2 * NB row buffers [PW][CS] fp32
-    const int nsl = hid.c / CS, H = hid.h, W = hid.w;
+    const int nsl = nhl * (512 / CS), H = hid.h, W = hid.w;
     int b = blockIdx.x;
     const int sl = b % nsl; b /= nsl;
     const int half = b % plan.halves, grp = b / plan.halves, G = gridDim.x / (nsl * plan.halves);   // images grp, grp + G, ...
     const H2UHalf hf = half ? plan.h[1] : plan.h[0];
-    const int hd = sl / (512 / CS), cbase = (sl % (512 / CS)) * CS;
+    const int hd = hd0 + sl / (512 / CS), cbase = (sl % (512 / CS)) * CS;
     const int pl = threadIdx.x / LPP, ch = threadIdx.x % LPP, c0 = cbase + ch * V;
     const int px = hf.px_lo + pl;
     const bool active = pl < hf.px_n, owner = active && px >= hf.own_lo && px < hf.own_hi;
@@ -1210,10 +1221,10 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
         }
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 acc[8][V / 2];
-    float bs[8], w[8][V], va[V], vb[V];
+    f32x2 acc[KJ][V / 2];
+    float bs[KJ], w[8][V], va[V], vb[V];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < KJ; ++j) {
         bs[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < V / 2; ++i) acc[j][i] = (f32x2){0.f, 0.f};
@@ -1223,7 +1234,7 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
     { int k; head2_load_w<V>(ha, hd, c0, active, w, k); }
     if (nostore) {                                                      // the consumers generate d_hid with W2 in the compute dtype (GenHid): the same values here
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < KJ; ++j)
 #pragma unroll
             for (int i = 0; i < V; ++i) w[j][i] = to_f32(from_f32<T>(w[j][i]));
     }
@@ -1289,12 +1300,12 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
             // The loads are unconditional (rows past the end re-read the last row, idle lanes the last pixel column): a load under a
             // condition makes its destination a phi, the compiler copies it at the end of the block and WAITS for the load there -- the
             // row just requested instead of the one needed D rows later
-            float gj[8], h[V];
+            float gj[KJ], h[V];
             {
                 const T* ge = (const T*)&graw[d];
                 const T* he = (const T*)&hraw[d];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) gj[j] = to_f32(ge[j]);
+                for (int j = 0; j < KJ; ++j) gj[j] = to_f32(ge[j]);
 #pragma unroll
                 for (int i = 0; i < V; ++i) h[i] = to_f32(he[i]);
             }
@@ -1315,7 +1326,7 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
 #pragma unroll
                     for (int i = 0; i < V; ++i) o[i] = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
+                    for (int j = 0; j < KJ; ++j) {
                         bs[j] += gj[j];
                         const f32x2 g2 = {gj[j], gj[j]};
 #pragma unroll
@@ -1358,7 +1369,7 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
     }
     if (!owner) {                                                       // idle lanes and the other half's columns
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < KJ; ++j) {
             bs[j] = 0.f;
 #pragma unroll
             for (int i = 0; i < V / 2; ++i) acc[j][i] = (f32x2){0.f, 0.f};
@@ -1367,7 +1378,7 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
     // weight-gradient partial of this workgroup: the eight pixel columns of a wave by shuffles, the four waves through LDS, fixed order
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < KJ; ++j) {
 #pragma unroll
         for (int i = 0; i < V; ++i) {
             float a = acc[j][i >> 1][i & 1];
@@ -1382,13 +1393,18 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
     float* red = s_v;                                                   // [wave][j][64 channels] + [wave][8] bias sums
     if (lane < LPP) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < KJ; ++j) {
             *(f32x4*)&red[(wv * 8 + j) * CS + lane * V] = (f32x4){acc[j][0][0], acc[j][0][1], acc[j][1][0], acc[j][1][1]};
             *(f32x4*)&red[(wv * 8 + j) * CS + lane * V + 4] = (f32x4){acc[j][2][0], acc[j][2][1], acc[j][3][0], acc[j][3][1]};
         }
+#pragma unroll
+        for (int j = KJ; j < 8; ++j) {                                  // (rows past the launch's k: zeros, the reduction reads all eight)
+            *(f32x4*)&red[(wv * 8 + j) * CS + lane * V] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)&red[(wv * 8 + j) * CS + lane * V + 4] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
         if (lane == 0) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) red[4 * 8 * CS + wv * 8 + j] = bs[j];
+            for (int j = 0; j < 8; ++j) red[4 * 8 * CS + wv * 8 + j] = j < KJ ? bs[j < KJ ? j : 0] : 0.f;
         }
     }
     __syncthreads();
@@ -1401,13 +1417,13 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
             float o = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) o += red[(q * 8 + j) * CS + c];
-            partial[(blk * nh * 8 + hd * 8 + j) * 512 + cbase + c] = o;
+            partial[(blk * nhl * 8 + (hd - hd0) * 8 + j) * 512 + cbase + c] = o;
         }
         if (cbase == 0 && threadIdx.x < 8) {
             float bsum = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) bsum += red[4 * 8 * CS + q * 8 + threadIdx.x];
-            bpartial[blk * 32 + hd * 8 + threadIdx.x] = bsum;
+            bpartial[blk * 32 + (hd - hd0) * 8 + threadIdx.x] = bsum;
         }
     }
 }
@@ -1460,23 +1476,50 @@ static int head2_backward_up_t(const dbx_view* dout, const dbx_view* hid, const 
             ha.w2[i] = i < nh ? w2[i] : nullptr; ha.k[i] = i < nh ? k[i] : 0;
             if (i < nh) DBX_REQUIRE(k[i] >= 1 && k[i] <= 8 && dw[i] && w2[i] && ((size_t)w2[i] % 16) == 0, "head2_backward_up: k in 1..8, 16-byte aligned weights");
         }
-        // two workgroups per CU (248 VGPRs x 256 threads): `groups` workgroups per (channel slice, half), each walking every groups-th image
-        const int nsl = hid->c / 64;
-        int groups = H2U_WGS / (nsl * plan.halves);
-        groups = groups < 1 ? 1 : groups > hid->n ? hid->n : groups;
-        const int blocks = groups * plan.halves;                        // <= 2 n <= n h and <= 512 / nsl: inside dbx_head2_wgrad_scratch_bytes
-        float* partial = (float*)scratch;
-        float* bpartial = partial + (size_t)blocks * nh * 8 * 512;
+        // One launch per run of consecutive heads with the same k rounded up to 1 / 2 / 4 / 8 (round 4: the kernel is VALU-bound --
+        // ~250 instructions per row and wave with all eight d_out channels multiplied out -- and the heads have k = 1, 4, 4, 8: the
+        // k = 1 launch runs 36 % fewer, the k = 4 launch 21 % fewer; DBX_HEAD2_UP_SPLIT=0: one launch with eight channels).
+        // Two workgroups per CU (248 VGPRs x 256 threads): `groups` workgroups per (channel slice, half), each walking every groups-th image.
         constexpr size_t smem = (size_t)2 * H2U_NB * 32 * 64 * 4;       // the ring (>= the 4 x 8 x 64 + 32 floats of the final reduction)
         static_assert(smem >= (4 * 8 * 64 + 32) * 4 && 2 * smem + 4096 <= 160 * 1024, "LDS budget of two workgroups per CU");
         static DbxDevOnce attr_once; int attr_dev = 0;
         if (attr_once.pending(&attr_dev)) {
-            DBX_HIP(hipFuncSetAttribute((const void*)head2_backward_up_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            DBX_HIP(hipFuncSetAttribute((const void*)head2_backward_up_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            DBX_HIP(hipFuncSetAttribute((const void*)head2_backward_up_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            DBX_HIP(hipFuncSetAttribute((const void*)head2_backward_up_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            DBX_HIP(hipFuncSetAttribute((const void*)head2_backward_up_kernel<T, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             attr_once.mark(attr_dev);
         }
-        hipLaunchKernelGGL(head2_backward_up_kernel<T>, dim3(blocks * nsl), dim3(256), smem, s, make_geo<T>(dout), make_geo<T>(hid), make_geo<T>(nostore ? hid : dhid),
-                           make_geo<T>(dg), nh, dout->c / nh, ha, partial, bpartial, mask, mask_ld, use_hash, drop_seed, sy, sx, plan, nostore ? 1 : 0);
-        DBX_LAUNCH_CHECK();
+        static int split = -1;
+        if (split < 0) { const char* e = getenv("DBX_HEAD2_UP_SPLIT"); split = e ? atoi(e) : 1; }
+        auto kup = [&](int kk) { return !split ? 8 : kk <= 1 ? 1 : kk <= 2 ? 2 : kk <= 4 ? 4 : 8; };
+        float* const pbase = (float*)scratch;
+        long long pused = 0;                                            // floats of the scratch handed out
+        int blocks_max = 0;
+        for (int h0 = 0; h0 < nh;) {
+            int h1 = h0 + 1;
+            while (h1 < nh && kup(k[h1]) == kup(k[h0])) ++h1;
+            const int nhl = h1 - h0, nsl = nhl * 8, kj = kup(k[h0]);
+            int groups = H2U_WGS / (nsl * plan.halves);
+            groups = groups < 1 ? 1 : groups > hid->n ? hid->n : groups;
+            const int blocks = groups * plan.halves;                    // <= 2 n <= n h: all launches together stay inside dbx_head2_wgrad_scratch_bytes
+            float* partial = pbase + pused;
+            float* bpartial = partial + (size_t)blocks * nhl * 8 * 512;
+            for (int i = h0; i < h1; ++i) { o.poff[i] = pused; o.boff[i] = pused + (long long)blocks * nhl * 8 * 512; o.nblk[i] = blocks; o.nhl[i] = nhl; o.hl[i] = i - h0; }
+            pused += (long long)blocks * (nhl * 8 * 512 + 32);
+            blocks_max = blocks > blocks_max ? blocks : blocks_max;
+#define H2U_LAUNCH(KJ)                                                                                                              \
+            hipLaunchKernelGGL((head2_backward_up_kernel<T, KJ>), dim3(blocks * nsl), dim3(256), smem, s, make_geo<T>(dout), make_geo<T>(hid),    \
+                               make_geo<T>(nostore ? hid : dhid), make_geo<T>(dg), h0, nhl, dout->c / nh, ha, partial, bpartial, mask, mask_ld,    \
+                               use_hash, drop_seed, sy, sx, plan, nostore ? 1 : 0)
+            if (kj == 1) H2U_LAUNCH(1); else if (kj == 2) H2U_LAUNCH(2); else if (kj == 4) H2U_LAUNCH(4); else H2U_LAUNCH(8);
+#undef H2U_LAUNCH
+            DBX_LAUNCH_CHECK();
+            h0 = h1;
+        }
+        for (int i = nh; i < 4; ++i) { o.poff[i] = 0; o.boff[i] = 0; o.nblk[i] = 0; o.nhl[i] = 1; o.hl[i] = 0; }
+        float* partial = pbase; float* bpartial = pbase;                // (the reduction takes each head's offsets from o)
+        const int blocks = blocks_max;
         const int total = nh * 8 * 512 + nh * 8;
         hipLaunchKernelGGL(head2_wgrad_reduce_kernel, dim3((total + 63) / 64), dim3(1024), 0, s, partial, bpartial, blocks, nh, o);
         DBX_LAUNCH_CHECK();
