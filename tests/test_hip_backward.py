@@ -306,3 +306,40 @@ def test_refine_branch_by_linearity_equals_the_three_convs(golden, dtype, monkey
     for k in ga:
         rel = float((ga[k].double() - gb[k].double()).norm() / (gb[k].double().norm() + 1e-30))
         assert rel <= tol, (k, rel)
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'f16'])
+def test_heads_backward_with_generated_hidden_gradient_equals_the_in_memory_form(golden, dtype, monkeypatch):
+    """Default 16-bit training plans hold no hidden-gradient buffer: dbx_head2_backward_up leaves d_hid out and its two 60x60 consumers
+    generate it (dbx_heads1_wgrad_gen / dbx_heads1_dgrad_gen).  Against DBX_HEADS_GEN=0 (d_hid written and read back), same hash-dropout
+    seed: identical loss (the forward is the same), gradients equal up to the rounding of W2 to the compute dtype inside the
+    generating MFMAs (the in-memory form multiplies by the fp32 W2)."""
+    g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', dtype)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.5
+    net.dropout_masks = None
+
+    def grads(flag):
+        monkeypatch.setenv('DBX_HEADS_GEN', flag)
+        eng = net.engine()
+        eng.plans = {}
+        torch.manual_seed(1234)
+        eng._seed_state = None
+        for p in net.parameters():
+            p.grad = None
+        _, loss = _step(g, kind, net, n, x, 0)
+        loss.backward()
+        P = eng.last_plan
+        assert P.drop_hash and P.heads_gen == (flag == '1') and ('d_hid' in P.B) == (flag == '0')
+        return float(loss.detach()), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    la, ga = grads('1')
+    lb, gb = grads('0')
+    assert la == lb and set(ga) == set(gb)
+    tol = 6e-3 if dtype == 'f16' else 4e-2
+    worst = 0.0
+    for k in ga:
+        rel = float((ga[k].double() - gb[k].double()).norm() / (gb[k].double().norm() + 1e-30))
+        worst = max(worst, rel)
+        assert rel <= tol, (k, rel)
+    assert worst > 0            # (the two forms are different kernels)
