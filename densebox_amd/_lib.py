@@ -64,6 +64,7 @@ SIGNATURES = {
     'dbx_heads_forward_fusable': (C.c_int, [_PC, _PV, _PV, C.POINTER(C.c_int32), _I32]),
     'dbx_heads_forward_fused_scratch_bytes': (_I64, [_I32, _I64]),
     'dbx_heads_forward_fused': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _VP, _VP, C.POINTER(C.c_int32), _I32, _VP, _VP, _VP]),
+    'dbx_heads_forward_fused_heads': (C.c_int, [_PC, _PV, _VP, _VP, _PV, _VP, _VP, C.POINTER(C.c_int32), _I32, C.POINTER(C.c_void_p), _VP, _VP]),
     'dbx_dp_unique_id': (C.c_int, [_VP]),
     'dbx_dp_init': (C.c_int, [_VP, _I32, _I32, C.POINTER(C.c_void_p)]),
     'dbx_dp_allreduce_sum_f32': (C.c_int, [_VP, _VP, _I64, _VP]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     'dbx_refine_backward': (C.c_int, [_VP, _VP, _VP, _I32, _I32, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _I32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     'dbx_upsample_bilinear_nchw_f32': (C.c_int, [_VP, _I32, _I32, _I32, _VP, _I32, _I32, _VP]),
     'dbx_pack_multi': (C.c_int, [_I32, _VP, _I32, _I64, _VP]),
+    'dbx_sgd_pack_step': (C.c_int, [_I32, _VP, _I32, _I64, _VP, _F, _F, _F, _I32, _VP]),
     'dbx_head2_dgrad': (C.c_int, [_I32, _PV, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I32, _PV, _VP, _I32, _I32, C.c_uint32, _VP]),
     'dbx_head2_wgrad_scratch_bytes': (_I64, [_I32, _I32]),
     'dbx_head2_wgrad': (C.c_int, [_I32, _PV, _PV, C.POINTER(C.c_int32), _I32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _VP, _VP]),

@@ -1633,6 +1633,131 @@ extern "C" int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, in
     DBX_DISPATCH_DTYPE(dtype, pack_multi_t, jobs, count, (long long)max_elems, (hipStream_t)stream);
 }
 
+// ---------------------------------------------------------------------------------------------- SGD update + re-packing in one pass
+// After an optimizer step every parameter is read again to refresh its packed copies (pack_multi_kernel above: 53 us per step at batch 64
+// next to sgd_kernel's 43).  Here ONE job per parameter applies the update (dbx_sgd_update: the bits of sgd_kernel) while the 8 x 32 x
+// taps tile is staged in LDS and emits the chunks of ALL its packed images (forward, transposed, fragment-order, channel slices: up to
+// four destinations) from that tile: the parameter is read once, the gradient and the momentum buffer once, and no second launch follows.
+// pidx < 0: no gradient this step (the job only re-packs).  ndst == 0: a parameter nobody packs (plain update).
+struct PackDst { void* dst; long long ktot; int mode, cin_pad, row_off, k_off, rows_lim, pad_; };     // as PackJob's destination fields
+struct SgdPackJob { float* p; int pidx, co, ci, taps, ndst, tiled; PackDst d[4]; };
+template <typename T>
+__device__ __forceinline__ void pack_scatter_elem(const PackDst& d, int o, int c, int t, int i, int taps, float v) {
+    if (d.mode == 2) { ((float*)d.dst)[d.row_off + i] = v; return; }
+    const bool fwd = d.mode == 0 || d.mode == 4;
+    const int rl = d.mode >= 4 ? (int)d.ktot : d.rows_lim;
+    const int row = d.row_off + (fwd ? o : c), col = d.k_off + (fwd ? c : o), tap = fwd ? t : taps - 1 - t;
+    if (row < 0 || col < 0 || col >= d.cin_pad || (rl > 0 && row >= rl)) return;
+    T* wp = (T*)d.dst;
+    if (d.mode >= 4) wp[dbx_frag_index(row, tap, col, d.cin_pad, (int)d.ktot, taps)] = from_f32<T>(v);
+    else wp[(long long)row * d.ktot + (long long)tap * d.cin_pad + col] = from_f32<T>(v);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sgd_pack_kernel(const SgdPackJob* __restrict__ jobs, float* const* __restrict__ ptrs, float lr, float mu,
+                                                       float wd, int first) {
+    const SgdPackJob& j = jobs[blockIdx.y];
+    float* p = j.p;
+    const int pidx = j.pidx, taps = j.taps, ci = j.ci, co = j.co, ndst = j.ndst;
+    const float* g = pidx >= 0 ? ptrs[3 * pidx + 1] : nullptr;
+    float* b = pidx >= 0 ? ptrs[3 * pidx + 2] : nullptr;
+    const int total = co * ci * taps;
+    if (j.tiled && sizeof(T) == 2) {
+        // tile = 8 (o) x CW (c) x taps fp32 weights in LDS; CW = 32 for filters, 256 for 1x1 layers (their 32-channel tiles would hold 256
+        // numbers).  Staging keeps a batch of loads in flight per thread (the update's stores to p / buf would otherwise fence every
+        // following load: the pointers may alias as far as the compiler knows) and walks (row, offset) without a division.
+        __shared__ float tile[8][32 * 25];
+        const int CW = taps == 1 ? 256 : 32, nk8 = CW / 8;
+        const int ot = (co + 7) / 8, ctn = (ci + CW - 1) / CW, ntiles = ot * ctn, row_f = CW * taps;
+        constexpr int U = 3;
+        for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+            const int o0 = (tl / ctn) * 8, c0 = (tl % ctn) * CW;
+            const int cw = min(CW, ci - c0), ow = min(8, co - o0);
+            __syncthreads();
+            int r = 0, f = threadIdx.x;
+            while (f >= row_f) { f -= row_f; ++r; }
+            for (int e = threadIdx.x; e < 8 * row_f; e += U * 256) {
+                float pv[U], gv[U], bv[U];
+                int ii[U], rr[U], ff[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    rr[u] = r; ff[u] = f;
+                    const bool ok = r < ow && f < cw * taps;               // (r >= 8: past the tile -- ow <= 8)
+                    ii[u] = ok ? ((o0 + r) * ci + c0) * taps + f : -1;
+                    pv[u] = ok ? p[ii[u]] : 0.f;
+                    if (g && ok) { gv[u] = g[ii[u]]; bv[u] = first ? 0.f : b[ii[u]]; }
+                    f += 256;
+                    while (f >= row_f) { f -= row_f; ++r; }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (g && ii[u] >= 0) {
+                        float bb = bv[u];
+                        pv[u] = dbx_sgd_update(pv[u], gv[u], &bb, lr, mu, wd, first);
+                        b[ii[u]] = bb; p[ii[u]] = pv[u];
+                    }
+                    if (rr[u] < 8) tile[rr[u]][ff[u]] = pv[u];
+                }
+            }
+            __syncthreads();
+            for (int di = 0; di < ndst; ++di) {
+                const PackDst& d = j.d[di];
+                T* wp = (T*)d.dst;
+                const bool fwd = d.mode == 0 || d.mode == 4;
+                const int rl = d.mode >= 4 ? (int)d.ktot : d.rows_lim;
+                const int nch = fwd ? 8 * taps * nk8 : CW * taps;        // forward layouts: chunk = (o, tap, 8 c);  transposed: (c, tap, 8 o)
+                for (int q = threadIdx.x; q < nch; q += blockDim.x) {
+                    int row, col, tap;
+                    float v[8];
+                    if (fwd) {
+                        const int k8 = q % nk8, q2 = q / nk8, t = q2 % taps, r2 = q2 / taps;
+                        if (r2 >= ow || 8 * k8 >= cw) continue;
+                        row = d.row_off + o0 + r2; col = d.k_off + c0 + 8 * k8; tap = t;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = tile[r2][(8 * k8 + e) * taps + t];
+                    } else {
+                        const int c = q % CW, t = q / CW;
+                        if (c >= cw) continue;
+                        row = d.row_off + c0 + c; col = d.k_off + o0; tap = taps - 1 - t;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = tile[e][c * taps + t];
+                    }
+                    if (row < 0 || col < 0 || col + 8 > d.cin_pad || (rl > 0 && row >= rl)) continue;
+                    u32x4 raw;
+                    T* e8 = (T*)&raw;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) e8[e] = from_f32<T>(v[e]);
+                    const long long off = d.mode >= 4 ? (long long)dbx_frag_index(row, tap, col, d.cin_pad, (int)d.ktot, taps)
+                                                      : (long long)row * d.ktot + (long long)tap * d.cin_pad + col;
+                    *(u32x4*)(wp + off) = raw;
+                }
+            }
+        }
+        return;
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        float v = p[i];
+        if (g) { v = dbx_sgd_update(v, g[i], b + i, lr, mu, wd, first); p[i] = v; }
+        if (ndst == 0) continue;
+        const int q = i / taps, t = i - q * taps;
+        const int o = q / ci, c = q - o * ci;
+        for (int di = 0; di < ndst; ++di) pack_scatter_elem<T>(j.d[di], o, c, t, i, taps, v);
+    }
+}
+template <typename T> static int sgd_pack_t(const void* jobs, int count, long long max_elems, float* const* ptrs, float lr, float mu, float wd,
+                                            int first, hipStream_t s) {
+    int bx = (int)((max_elems + 255) / 256);
+    bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
+    hipLaunchKernelGGL(sgd_pack_kernel<T>, dim3(bx, count), dim3(256), 0, s, (const SgdPackJob*)jobs, ptrs, lr, mu, wd, first);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_sgd_pack_step(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, float* const* ptrs, float lr, float momentum,
+                                 float weight_decay, int32_t first_step, void* stream) {
+    DBX_REQUIRE(jobs && count > 0, "sgd_pack: empty job table");
+    static_assert(sizeof(PackDst) == 40 && sizeof(SgdPackJob) == 192, "job record layout (include/densebox_hip.h)");
+    DBX_DISPATCH_DTYPE(dtype, sgd_pack_t, jobs, count, (long long)max_elems, ptrs, lr, momentum, weight_decay, first_step, (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------- eval-mode head folding
 // The heads are Conv1x1(768->512) -> Dropout -> Conv1x1(512->k) with NO non-linearity (DenseBox.py:158-162); in eval
 // mode Dropout is the identity, so the pair is one linear map:  W = W2 W1  [k x 768],  b = W2 b1 + b2.

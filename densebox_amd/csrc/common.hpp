@@ -189,6 +189,16 @@ __host__ __device__ inline size_t dbx_frag_index(int row, int tap, int k, int ci
     return (blk * 64 + lane) * 8 + k % 8;
 }
 
+// torch.optim.SGD (dampening 0, no Nesterov; DenseBox.py:2001-2004) on one element: g = grad + wd p; buf = g (first step) | mu buf + g;
+// p -= lr buf.  No FMA contraction: sgd_kernel and sgd_pack_kernel must produce the same bits (and the ones torch's CPU loop does).
+__device__ __forceinline__ float dbx_sgd_update(float pv, float gr, float* buf, float lr, float mu, float wd, int first) {
+#pragma clang fp contract(off)
+    const float gv = gr + wd * pv;
+    const float bv = first ? gv : mu * *buf + gv;
+    *buf = bv;
+    return pv - lr * bv;
+}
+
 #define DBX_DISPATCH_DTYPE(dtype, FN, ...)                          \
     switch (dtype) {                                                \
         case DBX_F16: return FN<_Float16>(__VA_ARGS__);             \

@@ -1769,7 +1769,7 @@ extern "C" int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x,
 }
 
 // ---- heads forward, both 1x1 convs in one pass over the pixels (conv3x3_ws_kernel<T, 1, 1, 2>, see conv3x3_ws.hpp)
-struct Heads2Fin { int k[4], off[4], nh, ktot; };
+struct Heads2Fin { int k[4], off[4], nh, ktot; float* outp[4]; };   // outp[i] != NULL: head i's own [N][k_i][H][W] tensor
 __global__ void heads2_finish_kernel(const float* __restrict__ part, const float* __restrict__ bias2, float* __restrict__ out, int M, int HW,
                                      const Heads2Fin hf) {
     // out[n][off_i + m][r] = bias2[off_i + m] + part[2 i][p][m] + part[2 i + 1][p][m]   (a head's two 256-cout tiles, fixed order)
@@ -1786,7 +1786,10 @@ __global__ void heads2_finish_kernel(const float* __restrict__ part, const float
             const float s[8] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w, a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
 #pragma unroll
             for (int m = 0; m < 8; ++m)
-                if (m < hf.k[i]) out[((size_t)n * hf.ktot + hf.off[i] + m) * HW + r] = bias2[hf.off[i] + m] + s[m];
+                if (m < hf.k[i]) {
+                    float* o = hf.outp[i] ? hf.outp[i] + ((size_t)n * hf.k[i] + m) * HW + r : out + ((size_t)n * hf.ktot + hf.off[i] + m) * HW + r;
+                    *o = bias2[hf.off[i] + m] + s[m];
+                }
         }
     }
 }
@@ -1804,10 +1807,10 @@ extern "C" int dbx_heads_forward_fusable(const dbx_conv_desc* d, const dbx_view*
     return heads_fused_shape_ok(d, x, hid, k, nh) ? 1 : 0;
 }
 extern "C" int64_t dbx_heads_forward_fused_scratch_bytes(int32_t nh, int64_t pixels) { return (int64_t)2 * nh * pixels * 8 * 4 + 256; }
-extern "C" int dbx_heads_forward_fused(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,
-                                       const void* w2_frag, const float* bias2, const int32_t* k, int32_t nh, float* out_nchw,
-                                       void* scratch, void* stream) {
-    if (!d || !x || !hid || !w1_frag || !bias1 || !w2_frag || !bias2 || !k || !out_nchw || !scratch) { dbx_set_error("heads forward fused: null argument"); return DBX_ERR_ARG; }
+static int heads_forward_fused_impl(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,
+                                    const void* w2_frag, const float* bias2, const int32_t* k, int32_t nh, float* out_nchw, float* const* outs,
+                                    void* scratch, void* stream) {
+    if (!d || !x || !hid || !w1_frag || !bias1 || !w2_frag || !bias2 || !k || (!out_nchw && !outs) || !scratch) { dbx_set_error("heads forward fused: null argument"); return DBX_ERR_ARG; }
     DBX_REQUIRE((d->epilogue & DBX_CONV_WFRAG) && heads_fused_shape_ok(d, x, hid, k, nh),
                 "heads forward fused: needs the 16-bit 1x1 768 -> 512 nh GEMM the ws kernel takes (fragment-order weights, bias + hash dropout), nh <= 4 heads of <= 8 outputs");
     float* part = (float*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
@@ -1816,11 +1819,25 @@ extern "C" int dbx_heads_forward_fused(const dbx_conv_desc* d, const dbx_view* x
     else rc = conv_forward_t<__bf16>(d, x, w1_frag, bias1, hid, nullptr, nullptr, 0, (hipStream_t)stream, nullptr, nullptr, 0, 0, nullptr, nullptr, w2_frag, part);
     if (rc != DBX_OK) return rc;
     Heads2Fin hf; hf.nh = nh; hf.ktot = 0;
-    for (int i = 0; i < 4; ++i) { hf.k[i] = i < nh ? k[i] : 0; hf.off[i] = hf.ktot; hf.ktot += hf.k[i]; }
+    for (int i = 0; i < 4; ++i) {
+        hf.k[i] = i < nh ? k[i] : 0; hf.off[i] = hf.ktot; hf.ktot += hf.k[i];
+        hf.outp[i] = (outs && i < nh) ? outs[i] : nullptr;
+        if (outs && i < nh && !outs[i]) { dbx_set_error("heads forward fused: null head output"); return DBX_ERR_ARG; }
+    }
     const int M = hid->n * hid->h * hid->w, HW = hid->h * hid->w;
     hipLaunchKernelGGL(heads2_finish_kernel, dim3((M + 255) / 256 < 2048 ? (M + 255) / 256 : 2048), dim3(256), 0, (hipStream_t)stream, part, bias2, out_nchw, M, HW, hf);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
+}
+extern "C" int dbx_heads_forward_fused(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,
+                                       const void* w2_frag, const float* bias2, const int32_t* k, int32_t nh, float* out_nchw,
+                                       void* scratch, void* stream) {
+    return heads_forward_fused_impl(d, x, w1_frag, bias1, hid, w2_frag, bias2, k, nh, out_nchw, nullptr, scratch, stream);
+}
+extern "C" int dbx_heads_forward_fused_heads(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,
+                                             const void* w2_frag, const float* bias2, const int32_t* k, int32_t nh, float* const* outs,
+                                             void* scratch, void* stream) {
+    return heads_forward_fused_impl(d, x, w1_frag, bias1, hid, w2_frag, bias2, k, nh, nullptr, outs, scratch, stream);
 }
 
 // conv1_2 data gradient + conv1_1 weight gradient in one launch (conv3x3_c64_kernel<T, false, true>)

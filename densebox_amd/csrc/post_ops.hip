@@ -14,11 +14,7 @@ __global__ void sgd_kernel(float* const* __restrict__ ptrs, const long long* __r
     float* b = ptrs[3 * t + 2];
     const long long n = sizes[t];
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float pv = p[i];
-        const float gv = g[i] + wd * pv;
-        const float bv = first ? gv : mu * b[i] + gv;
-        b[i] = bv;
-        p[i] = pv - lr * bv;
+        p[i] = dbx_sgd_update(p[i], g[i], b + i, lr, mu, wd, first);
     }
 }
 extern "C" int dbx_sgd_step(float* const* ptrs, const int64_t* sizes, int32_t count, int64_t max_size, float lr, float momentum,

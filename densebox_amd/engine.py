@@ -6,6 +6,7 @@ network runs in the library.  Layer graph = DenseBox.py:180-228 / :412-473 / :67
 """
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -417,10 +418,76 @@ class Engine:
             for i, j in enumerate(jobs):
                 rec[i] = j
             dev = params[0].device
-            tab = (torch.from_numpy(rec.view(np.uint8).copy()).to(dev), len(jobs), max(j[2] * j[3] * j[4] for j in jobs))
+            tab = (torch.from_numpy(rec.view(np.uint8).copy()).to(dev), len(jobs), max(j[2] * j[3] * j[4] for j in jobs), jobs)
             self._tables = {tkey: tab}
+            self._sgd_tables = {}
         check(self.L.dbx_pack_multi(dt, ptr(tab[0]), tab[1], tab[2], stream_ptr()))
         self._wsig = sig
+        if train:
+            # optim.SGD.step() finds the engine through its parameters and folds the NEXT re-packing into the update (sgd_pack_step)
+            self._last_prep = (dt, tkey, lay)
+            ref = weakref.ref(self)
+            for p_ in params:
+                p_._dbx_engine = ref
+
+    def sgd_pack_step(self, live, ptrs, lr, momentum, weight_decay, first):
+        """optim.SGD.step() with this engine's re-packing folded in (dbx_sgd_pack_step): one job per parameter updates it and emits the packed
+        images the last training plan uses, so the next forward finds its weights packed and launches nothing.  `live`: the parameters with
+        gradients, in the order of `ptrs` ([param, grad, momentum] pointers on the device).  Returns False when the plain two-launch path
+        has to run (no training plan yet, parameters moved or changed behind the engine's back, DBX_SGD_PACK=0)."""
+        prep = getattr(self, '_last_prep', None)
+        if prep is None or self._wsig is None or os.environ.get('DBX_SGD_PACK', '1') == '0':
+            return False
+        dt, tkey, lay = prep
+        tab = self._tables.get(tkey)
+        params = [p for _, p in self.net.named_parameters()]
+        if tab is None or self._wsig[0] != dt or not self._wsig[1] or self._wsig[3] != lay:
+            return False
+        if tuple((p._version, p.data_ptr()) for p in params) != self._wsig[2]:
+            return False                                  # a parameter changed since the packed copies were made: the regular path re-packs
+        pidx = {p.data_ptr(): i for i, p in enumerate(live)}
+        skey = (tkey, tuple(pidx))
+        st = self._sgd_tables.get(skey)
+        if st is None:
+            import numpy as np
+            by_src, order = {}, []
+            for j in tab[3]:                              # (src, dst, co, ci, taps, mode, ktot, cin_pad, row_off, k_off, rows_lim)
+                if j[0] not in by_src:
+                    by_src[j[0]] = []
+                    order.append(j[0])
+                by_src[j[0]].append(j)
+            es = _lib.ESIZE[dt]
+            recs = []
+            for src in order:
+                js = by_src[src]
+                if src not in pidx:
+                    continue                              # no gradient: unchanged, its packed copies stay valid
+                if len(js) > 4 or len({(j[2], j[3], j[4]) for j in js}) != 1:
+                    return False
+                co, ci, taps = js[0][2], js[0][3], js[0][4]
+                tiled = es == 2 and taps <= 25 and all(
+                    j[5] != 2 and (ci if j[5] in (0, 4) else co) % 8 == 0 and j[9] % 8 == 0 and j[7] % 8 == 0 for j in js)
+                recs.append((src, pidx[src], co, ci, taps, len(js), int(tiled), js))
+            packed = set(order)
+            for p in live:                                # parameters nobody packs (the folded refine convs): plain update
+                if p.data_ptr() not in packed:
+                    recs.append((p.data_ptr(), pidx[p.data_ptr()], p.numel(), 1, 1, 0, 0, []))
+            dst_t = [('dst', '<u8'), ('ktot', '<i8'), ('mode', '<i4'), ('cin_pad', '<i4'), ('row_off', '<i4'), ('k_off', '<i4'),
+                     ('rows_lim', '<i4'), ('pad', '<i4')]
+            rec = np.zeros(len(recs), dtype=[('p', '<u8'), ('pidx', '<i4'), ('co', '<i4'), ('ci', '<i4'), ('taps', '<i4'), ('ndst', '<i4'),
+                                             ('tiled', '<i4'), ('d', dst_t, (4,))])
+            assert rec.dtype.itemsize == 192
+            for i, (src, pi, co, ci, taps, nd, tiled, js) in enumerate(recs):
+                rec[i]['p'], rec[i]['pidx'], rec[i]['co'], rec[i]['ci'], rec[i]['taps'] = src, pi, co, ci, taps
+                rec[i]['ndst'], rec[i]['tiled'] = nd, tiled
+                for k, j in enumerate(js):
+                    rec[i]['d'][k] = (j[1], j[6], j[5], j[7], j[8], j[9], j[10], 0)
+            st = (torch.from_numpy(rec.view(np.uint8).copy()).to(params[0].device), len(recs), max(r[2] * r[3] * r[4] for r in recs))
+            self._sgd_tables = {skey: st}
+        check(self.L.dbx_sgd_pack_step(dt, ptr(st[0]), st[1], st[2], ptr(ptrs), lr, momentum, weight_decay, 1 if first else 0, stream_ptr()))
+        torch.autograd.graph.increment_version(live)
+        self._wsig = (dt, True, tuple((p._version, p.data_ptr()) for p in params), lay)
+        return True
 
     def _w_heads_folded(self, dt):
         """Eval mode: each head's two 1x1 convs folded into one 768->k map; all heads stacked into ONE [ktot x 768] GEMM."""
@@ -683,7 +750,7 @@ class Engine:
                 epi |= _lib.EPI_DROPMASK
             hfrag = (epi & _lib.EPI_DROPMASK) == 0 and self._frag_heads(P, dt, 'f')
             ktot = sum(k for _, k in heads)
-            big = torch.empty((n, ktot, h4, w4), dtype=torch.float32, device=dev)
+            big = None
             b1 = self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
             b2 = self._bias(['conv5_2_' + s_ for s_, _ in heads], 64)
             if hfrag and P.drop_hash and self._heads_fused(P, dt):
@@ -697,9 +764,13 @@ class Engine:
                 if prof is not None:
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ev0.record()
-                check(L.dbx_heads_forward_fused(C.byref(d), C.byref(B['fusion'].view()), ptr(self._w_heads1(dt, frag=True)), ptr(b1),
-                                                C.byref(B['hid'].view()), ptr(self._w_heads2_frag(dt)), ptr(b2),
-                                                (C.c_int32 * nh)(*[k for _, k in heads]), nh, ptr(big), ptr(self._hf_scratch), s))
+                # every head's own contiguous [N][k][H][W] tensor, as the reference returns them (no slice copies)
+                for stem, k in heads:
+                    outs[stem] = torch.empty((n, k, h4, w4), dtype=torch.float32, device=dev)
+                check(L.dbx_heads_forward_fused_heads(C.byref(d), C.byref(B['fusion'].view()), ptr(self._w_heads1(dt, frag=True)), ptr(b1),
+                                                      C.byref(B['hid'].view()), ptr(self._w_heads2_frag(dt)), ptr(b2),
+                                                      (C.c_int32 * nh)(*[k for _, k in heads]), nh,
+                                                      (C.c_void_p * nh)(*[outs[stem].data_ptr() for stem, _ in heads]), ptr(self._hf_scratch), s))
                 if prof is not None:
                     ev1.record()
                     prof.append({'kernel': 'conv3x3_ws_kernel<%s,1,1,2>' % ('f16', 'bf16', 'f32')[dt],
@@ -710,12 +781,14 @@ class Engine:
                            dropmask=dm, dm_ld=512 * nh, drop_seed=P.drop_seed if P.drop_hash else 0)
                 # stage 2: the nh Conv1x1(512 -> k) as ONE block-diagonal GEMM 512 nh -> sum(k) over the full hidden rows (4 KiB contiguous
                 # per pixel instead of four strided 1-KiB slices in four launches); the heads' outputs are channel ranges of one tensor
+                big = torch.empty((n, ktot, h4, w4), dtype=torch.float32, device=dev)
                 yv = View(C.c_void_p(big.data_ptr()), n, h4, w4, 0, ktot, 0, ktot)
                 self._conv(dt, B['hid'].view(), yv, self._w_heads2(dt), b2, 1, 1, 0,
                            512 * nh, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW, alg_ci=512)
             o = 0
             for stem, k in heads:
-                outs[stem] = big[:, o:o + k].contiguous()
+                if big is not None:
+                    outs[stem] = big[:, o:o + k].contiguous()
                 o += k
         lin_rf = os.environ.get('DBX_REFINE_LINEAR', '1') != '0'     # training: the branch by its linear structure (0: the three convs; A/B, tests)
         P.refine_fwd = None

@@ -1,6 +1,7 @@
 """Fused multi-tensor SGD with the semantics of the reference's optimizer
 (``torch.optim.SGD(net.parameters(), lr, momentum=0.9, weight_decay=5e-8)``, DenseBox.py:2001-2004)
-and its epoch schedule ``adjust_LR`` (DenseBox.py:1345-1365).  One HIP launch updates every tensor."""
+and its epoch schedule ``adjust_LR`` (DenseBox.py:1345-1365).  One HIP launch updates every tensor -- and, for the parameters of a
+network that has run a training step on the HIP engine, also refreshes the packed 16-bit copies its next forward needs."""
 import ctypes as C
 
 import torch
@@ -48,6 +49,13 @@ class SGD:
             self._key = key
         ptrs, sizes, mx = self._table
         with torch.no_grad():
+            # parameters of a network whose HIP engine has run a training step: the update and the re-packing of the weights for the
+            # next forward are ONE launch (engine.sgd_pack_step -> dbx_sgd_pack_step; same bits as the two launches)
+            refs = {id(getattr(p, '_dbx_engine', None)) for p in live}
+            eng = getattr(live[0], '_dbx_engine', None) if len(refs) == 1 else None
+            eng = eng() if eng is not None else None
+            if eng is not None and eng.sgd_pack_step(live, ptrs, g['lr'], g['momentum'], g['weight_decay'], bool(first)):
+                return
             check(_lib.lib().dbx_sgd_step(ptr(ptrs), ptr(sizes), len(live), mx, g['lr'], g['momentum'],
                                           g['weight_decay'], 1 if first else 0, stream_ptr()))
             # the kernel wrote the parameters behind autograd's back: bump their version counters so that

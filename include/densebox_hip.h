@@ -116,6 +116,11 @@ int64_t dbx_heads_forward_fused_scratch_bytes(int32_t nh, int64_t pixels);
 int dbx_heads_forward_fused(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,
                             const void* w2_frag, const float* bias2, const int32_t* k, int32_t nh, float* out_nchw, void* scratch,
                             void* stream);
+/* The same with one destination per head, as the reference's forward returns them (DenseBox.py:223-224): outs[i] = head i's own
+ * contiguous fp32 [N][k_i][H][W] tensor (host array of nh device pointers).  Saves the caller the nh slice copies out of [N][sum k][H][W]. */
+int dbx_heads_forward_fused_heads(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,
+                                  const void* w2_frag, const float* bias2, const int32_t* k, int32_t nh, float* const* outs, void* scratch,
+                                  void* stream);
 
 /* 1x1 GEMM (16-bit types) with a split destination: couts [0, split_c) go to y with d->epilogue / gate, couts
  * [split_c, split_c + y2->c) to y2 with epilogue2 (plain, GATE and/or ACCUM) / gate2.  split_c = y->c, a multiple of 256.
@@ -161,6 +166,18 @@ int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw, int32_t co
  * mode 0/1/4/5 as dbx_pack_weight (4/5: ktot carries rows_pad; out-of-range destinations are skipped), mode 2 = fp32 bias copy
  * into dst[row_off ...] (co = length, ci = taps = 1). */
 int dbx_pack_multi(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, void* stream);
+
+/* The optimizer step (dbx_sgd_step, below) AND the re-packing in one launch (round 4): one job per parameter updates it -- the bits of
+ * dbx_sgd_step -- while its tiles are staged and emits ALL of its packed images from them (the parameter, its gradient and its
+ * momentum buffer are read once; replaces dbx_sgd_step + dbx_pack_multi after a training step).  `jobs` is a device array of 192-byte records
+ *   struct { float* p; int32 pidx, co, ci, taps, ndst, tiled;
+ *            struct { void* dst; int64 ktot; int32 mode, cin_pad, row_off, k_off, rows_lim, pad; } d[4]; }
+ * p = the fp32 OIHW parameter; pidx = its index in `ptrs` (the table dbx_sgd_step takes: [param, grad, momentum] x count; pidx < 0:
+ * no gradient this step, the job only re-packs); d[0 .. ndst) = its destinations, fields as in dbx_pack_multi's record (ndst = 0: plain
+ * update); tiled = 1 where every destination is a 16-bit image with 8-aligned offsets / paddings, its K index over a multiple of 8 source
+ * channels and taps <= 25 (the staged-tile path; 0 = element-wise).  max_elems = the largest co ci taps. */
+int dbx_sgd_pack_step(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, float* const* ptrs, float lr, float momentum,
+                      float weight_decay, int32_t first_step, void* stream);
 
 /* heads: data gradient of the nh (<= 4) Conv1x1(512->k_h) layers behind Dropout in one rank-k streaming pass:
  * d_hid[m, 512h+c] = keep(m, 512h+c) * sum_{j<k_h} d_out[m, slot*h + j] * w2[h][j][c];  keep = 2*mask[..] (dropmask buffer),

@@ -343,3 +343,61 @@ def test_heads_backward_with_generated_hidden_gradient_equals_the_in_memory_form
         worst = max(worst, rel)
         assert rel <= tol, (k, rel)
     assert worst > 0            # (the two forms are different kernels)
+
+
+@pytest.mark.parametrize('dtype', ['f16', 'bf16', 'f32'])
+@pytest.mark.parametrize('name', ['train_DenseBoxLMLOC', 'train_DenseBox'])
+def test_sgd_with_repacking_folded_in_equals_update_then_pack(golden, name, dtype, monkeypatch):
+    """optim.SGD.step() on an engine's parameters is ONE launch (dbx_sgd_pack_step: the update and every packed image of every parameter);
+    DBX_SGD_PACK=0 keeps dbx_sgd_step + dbx_pack_multi.  Three steps each way from the same start (momentum on, a weight decay large
+    enough to show): losses, parameters, momentum buffers and every packed weight / bias image must be bitwise equal, the fused run must
+    not launch the re-packing (the engine's signature is current after step()), and a parameter changed behind the engine's back falls
+    back to the regular path."""
+    runs = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('DBX_SGD_PACK', mode)
+        g, kind, net, n, x = _setup(golden, name, dtype)
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        net.dropout_masks = None
+        opt = SGD(net.parameters(), lr=2e-9, momentum=0.9, weight_decay=1e-3)
+        eng = net.engine()
+        losses, fused = [], []
+        for it in range(3):
+            opt.zero_grad()
+            _, loss = _step(g, kind, net, n, x, 0)
+            loss.backward()
+            sig = eng._wsig
+            opt.step()
+            fused.append(eng._wsig is not sig)             # the fused step installs the post-update signature
+            losses.append(float(loss.detach()))
+        # the next forward's weights, as the engine will use them
+        with torch.no_grad():
+            outs = net(x[:n].cuda())
+        torch.cuda.synchronize()
+        packed = {str(k): v[1].clone() for k, v in eng.wcache.items() if torch.is_tensor(v[1])}
+        packed.update({'b' + str(k): v[1].clone() for k, v in eng.bias_cache.items()})
+        runs[mode] = (losses, {k: p.detach().clone() for k, p in net.named_parameters()},
+                      [opt.bufs[id(p)].clone() for p in opt.params if id(p) in opt.bufs], packed, [o.clone() for o in outs], fused)
+    a, b = runs['1'], runs['0']
+    assert all(a[5]) and not any(b[5])
+    assert a[0] == b[0] and a[0][0] != a[0][2]
+    for k in a[1]:
+        assert bool(torch.isfinite(a[1][k]).all()) and torch.equal(a[1][k], b[1][k]), k
+    assert len(a[2]) == len(b[2]) and all(torch.equal(u, v) for u, v in zip(a[2], b[2]))
+    assert set(a[3]) == set(b[3]) and len(a[3]) > 20
+    for k in a[3]:
+        assert torch.equal(a[3][k], b[3][k]), k
+    assert all(torch.equal(u, v) for u, v in zip(a[4], b[4]))
+    # a parameter written behind the engine's back: the fused path declines, the regular path re-packs
+    monkeypatch.setenv('DBX_SGD_PACK', '1')
+    g, kind, net, n, x = _setup(golden, name, dtype)
+    opt = SGD(net.parameters(), lr=2e-9, momentum=0.9, weight_decay=1e-3)
+    _, loss = _step(g, kind, net, n, x, 0)
+    loss.backward()
+    with torch.no_grad():
+        next(net.parameters()).mul_(1.0)
+    sig = net.engine()._wsig
+    opt.step()
+    assert net.engine()._wsig is sig

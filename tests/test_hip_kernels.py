@@ -908,7 +908,13 @@ def test_heads_forward_fused_equals_the_two_gemms(ks, n, h, w, dtn):
     yv = View(C.c_void_p(out_b.data_ptr()), n, h, w, 0, ktot, 0, ktot)
     dd = ConvDesc(dt, 1, 1, 0, 512 * nh, 64, _lib.EPI_BIAS | _lib.EPI_F32_NCHW)
     check(L.dbx_conv_forward(C.byref(dd), C.byref(hvb), ptr(w2b), ptr(b2), C.byref(yv), None, None, 0, stream_ptr()))
+    # one destination per head (dbx_heads_forward_fused_heads): bitwise the channel slices of the [N][sum k][H][W] form
+    outs_h = [torch.full((n, k, h, w), 7.0, device='cuda') for k in ks]
+    fc, tc, hvc = framed(torch.zeros(n, 512 * nh, h, w), 0, tdt)
+    check(L.dbx_heads_forward_fused_heads(C.byref(d), C.byref(xv), ptr(w1f), ptr(b1), C.byref(hvc), ptr(w2f), ptr(b2), karr, nh,
+                                          (C.c_void_p * nh)(*[o.data_ptr() for o in outs_h]), ptr(sc), stream_ptr()))
     torch.cuda.synchronize()
+    assert torch.equal(fa, fc) and torch.equal(torch.cat(outs_h, 1), out_a)
     assert torch.equal(fa, fb) and float(ta.float().abs().sum()) > 0
     scale = float(out_b.abs().max())
     assert float((out_a - out_b).abs().max()) <= 2e-5 * scale, (float((out_a - out_b).abs().max()), scale)
