@@ -6,7 +6,7 @@ import torch
 from conftest import unpack
 import densebox_amd.labels as LB
 from densebox_amd.loss import densebox_loss
-from densebox_amd import _lib
+from densebox_amd import _lib, synth
 from oracle import densebox_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -152,3 +152,34 @@ def test_mining_paths_match_the_oracle_for_small_and_large_k(golden, half):
     for o, l in zip(outs, leaf):
         ref = l.grad.numpy()
         assert np.allclose(o.grad.cpu().numpy(), ref, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref).max()))
+
+
+def test_all_negative_batch_has_no_mined_negatives():
+    """A batch without a single positive patch (DenseBox.py:2074: neg_num = int(0 / N + 0.5) = 0; only train_densebox_online, whose labels
+    say so -- the bbox-driven loops always find the pixel of an all-zero box): nothing is mined, the score / bbox maps contribute no loss and
+    no gradient, the landmark channels keep their one random negative each -- loss, index lists (empty) and dL/dout against the oracle."""
+    n, kind = 3, 'DenseBoxLMLOC'
+    x, bbox, vert, lab = synth.synth_batch(n, seed=5, neg_frac=1.0)
+    assert int(LB.positive_count(bbox, lab).sum()) == 0 and LB.neg_counts(0, n) == (0, 0)
+    assert int(LB.positive_count(bbox, None).sum()) == n           # (the bbox-driven count: one pixel per all-zero box)
+    rs = np.random.RandomState(3)
+    shapes = [(n, 1, 60, 60), (n, 4, 60, 60)] if kind == 'DenseBox' else [(n, 1, 60, 60), (n, 1, 60, 60), (n, 4, 60, 60), (n, 4, 60, 60), (n, 8, 60, 60)]
+    outs_np = [rs.randn(*sh).astype(np.float32) for sh in shapes]
+    rand_neg = np.zeros((n, 0), dtype=np.int64)
+    lm_rand = None if kind == 'DenseBox' else np.stack([np.stack([rs.choice(3600, 1, replace=False) for _ in range(n)]) for _ in range(4)])
+    outs = [T(o).cuda().requires_grad_(True) for o in outs_np]
+    loss, dbg = densebox_loss(kind, tuple(outs), bbox.numpy(), vert.numpy(), lab.numpy(), rand_neg_indices=rand_neg,
+                              lm_rand_neg_indices=lm_rand, return_debug=True)
+    leaf = [T(o).requires_grad_(True) for o in outs_np]
+    res = O.loss_step(kind, tuple(leaf), bbox.numpy(), vert.numpy(), lab.numpy(), rand_neg=rand_neg, lm_rand_neg=lm_rand)
+    assert dbg['half'] == 0 == res['half'] and dbg['neg_idx'].numel() == 0 and res['neg_idx'].size == 0
+    assert np.array_equal(dbg['mask_cls'].cpu().numpy(), res['mask']) and not res['mask'].any()
+    lo = float(res['loss'].detach())
+    assert abs(float(loss.detach()) - lo) <= 2e-6 * max(1.0, abs(lo))
+    loss.backward()
+    if res['loss'].requires_grad:
+        res['loss'].backward()
+    for o, l in zip(outs, leaf):
+        ref = l.grad.numpy() if l.grad is not None else np.zeros(o.shape, np.float32)
+        got = o.grad.cpu().numpy() if o.grad is not None else np.zeros(o.shape, np.float32)
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 * max(1.0, np.abs(ref).max()))
