@@ -40,8 +40,10 @@ const char* dbx_last_error(void);
  * an argument list or a scratch-size contract changes (a binding must refuse a library whose version differs):
  *   2  (round 3) dbx_loss_forward_backward's scratch grew from n doubles to dbx_loss_scratch_bytes(n) (mask planes + partial sums);
  *      the dbx_pack_multi job record's former pad field became rows_lim
- *   3  (round 4) fused entry points added (see the round-4 section below); nothing removed */
-#define DBX_ABI_VERSION 4
+ *   3  (round 4) fused entry points added (see the round-4 section below); nothing removed
+ *   4  (round 4) dbx_head2_backward_up takes a d_hid view with a NULL ptr ("do not store it"); heads-gen entry points added
+ *   5  (round 4) dbx_sgd_pack_step and dbx_heads_forward_fused_heads added; nothing changed */
+#define DBX_ABI_VERSION 5
 int dbx_version(void);
 /* device sanity: returns gfx arch number (950) of `device`, or <0 */
 int dbx_device_arch(int device);
