@@ -172,6 +172,36 @@ class Plan:
         self.B = B
 
 
+# parameter -> engine, for optim.SGD.step() (which is handed bare parameters, like torch.optim.SGD): a registry on the side instead of an
+# attribute on the Parameter (attributes travel with deepcopy / pickle of the module; a weak reference does not pickle)
+_PARAM_ENGINE = {}
+
+
+def register_params(engine, params):
+    if len(_PARAM_ENGINE) > 4096:
+        for k in [k for k, (rp, re_) in _PARAM_ENGINE.items() if rp() is None or re_() is None]:
+            del _PARAM_ENGINE[k]
+    re_ = weakref.ref(engine)
+    for p in params:
+        ent = _PARAM_ENGINE.get(id(p))
+        if ent is None or ent[0]() is not p or ent[1]() is not engine:
+            _PARAM_ENGINE[id(p)] = (weakref.ref(p), re_)
+
+
+def engine_of(params):
+    """The one engine all of `params` were registered by (a training-mode forward), or None."""
+    eng = None
+    for p in params:
+        ent = _PARAM_ENGINE.get(id(p))
+        if ent is None or ent[0]() is not p:
+            return None
+        e = ent[1]()
+        if e is None or (eng is not None and e is not eng):
+            return None
+        eng = e
+    return eng
+
+
 class Engine:
     def __init__(self, net):
         self.net = net
@@ -426,9 +456,7 @@ class Engine:
         if train:
             # optim.SGD.step() finds the engine through its parameters and folds the NEXT re-packing into the update (sgd_pack_step)
             self._last_prep = (dt, tkey, lay)
-            ref = weakref.ref(self)
-            for p_ in params:
-                p_._dbx_engine = ref
+            register_params(self, params)
 
     def sgd_pack_step(self, live, ptrs, lr, momentum, weight_decay, first):
         """optim.SGD.step() with this engine's re-packing folded in (dbx_sgd_pack_step): one job per parameter updates it and emits the packed
@@ -445,6 +473,9 @@ class Engine:
             return False
         if tuple((p._version, p.data_ptr()) for p in params) != self._wsig[2]:
             return False                                  # a parameter changed since the packed copies were made: the regular path re-packs
+        mine = {id(p) for p in params}
+        if any(id(p) not in mine for p in live):
+            return False                                  # the optimizer also holds parameters of something else
         pidx = {p.data_ptr(): i for i, p in enumerate(live)}
         skey = (tkey, tuple(pidx))
         st = self._sgd_tables.get(skey)

@@ -51,9 +51,8 @@ class SGD:
         with torch.no_grad():
             # parameters of a network whose HIP engine has run a training step: the update and the re-packing of the weights for the
             # next forward are ONE launch (engine.sgd_pack_step -> dbx_sgd_pack_step; same bits as the two launches)
-            refs = {id(getattr(p, '_dbx_engine', None)) for p in live}
-            eng = getattr(live[0], '_dbx_engine', None) if len(refs) == 1 else None
-            eng = eng() if eng is not None else None
+            from .engine import engine_of
+            eng = engine_of(live)
             if eng is not None and eng.sgd_pack_step(live, ptrs, g['lr'], g['momentum'], g['weight_decay'], bool(first)):
                 return
             check(_lib.lib().dbx_sgd_step(ptr(ptrs), ptr(sizes), len(live), mx, g['lr'], g['momentum'],

@@ -401,3 +401,9 @@ def test_sgd_with_repacking_folded_in_equals_update_then_pack(golden, name, dtyp
     sig = net.engine()._wsig
     opt.step()
     assert net.engine()._wsig is sig
+    # the engine finds its parameters through a registry on the side: nothing rides on the Parameter objects (they pickle / deep-copy)
+    import copy
+    import pickle
+    p0 = next(net.parameters())
+    assert not [k for k in vars(p0) if 'dbx' in k]
+    assert torch.equal(pickle.loads(pickle.dumps(p0)).cpu(), p0.detach().cpu()) and torch.equal(copy.deepcopy(p0), p0)
