@@ -1002,7 +1002,8 @@ class Engine:
         # Weight gradients are off the critical path (only dz -> dgrad -> next dz is a chain): they go to a side stream so
         # their workgroups fill the CUs that the data-gradient kernels' last rounds leave idle.  Every gradient producer and
         # its sink.ready() (which may launch an all-reduce ordered after the CURRENT stream) run on that stream; the main
-        # stream joins it before backward_raw returns.  Worth +0.6 % on one GPU; OPT-IN (DBX_SIDE_STREAM=1) because overlapping
+        # stream joins it before backward_raw returns.  Was worth +0.6 % in round 2; since the fused single-stream paths of rounds 3-4 (which it
+        # switches off) it is 4.6 % SLOWER than the default (profiles/r04_sgd_pack_ab.txt).  OPT-IN (DBX_SIDE_STREAM=1); overlapping
         # kernels make per-kernel durations in a rocprofv3 trace of the step meaningless, and never on while profiling.
         main = torch.cuda.current_stream()
         side = None
