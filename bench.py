@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 import densebox_amd as D                      # noqa: E402
 from densebox_amd import synth, labels as LB  # noqa: E402
-from densebox_amd.dist import init_from_env, DataParallel  # noqa: E402
+from densebox_amd.dist import init_from_env, DataParallel, preflight, report_failure  # noqa: E402
 from densebox_amd.optim import SGD            # noqa: E402
 
 # algorithmic FLOP per 240x240 patch (SURVEY.md 8d / BASELINE.md 2): forward, and forward+dgrad+wgrad
@@ -216,7 +216,17 @@ def self_launch(args):
         port = so.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd)
+    # rank 0's stdout passes through; a job that dies without a JSON line (a rank killed before it could report) still ends in one
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    seen = False
+    for line in proc.stdout:
+        seen = seen or line.startswith('{')
+        sys.stdout.write(line); sys.stdout.flush()
+    rc = proc.wait()
+    if rc != 0 and not seen:
+        from densebox_amd.dist import rccl_info
+        print(json.dumps({'error': 'launcher exited with code %d before rank 0 printed a line' % rc, 'rank': None, 'rccl': rccl_info()}), flush=True)
+    return rc
 
 
 def measured_peaks(dev, dtype):
@@ -260,6 +270,17 @@ def main():
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(self_launch(args))            # one rank per GPU; rank 0 of the child job prints the JSON line
+    try:
+        run(args)
+    except SystemExit:
+        raise
+    except BaseException as e:                 # a failed rendezvous / collective / launch: ONE parsable line, then the traceback
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1:
+            report_failure('bench.py --gpus %d failed' % args.gpus, e)
+        raise
+
+
+def run(args):
     rank, world, local = init_from_env()
     assert world == args.gpus, 'WORLD_SIZE=%d but --gpus %d' % (world, args.gpus)
     if args.dry_run:
@@ -281,6 +302,7 @@ def main():
     local = local % torch.cuda.device_count()          # (several ranks may share a GPU under DBX_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    preflight(dev)                                     # first collective under a watchdog: a broken RCCL set-up reports instead of hanging
     kind, n = args.kind, args.batch
 
     net = getattr(D, kind)(synth.vgg19_standin(seed=0))

@@ -7,14 +7,77 @@ concatenated global batch.  The one cross-sample coupling is ``neg_num = int(pos
 (DenseBox.py:2074), which uses the positives of the WHOLE batch: ranks all-reduce one int64 over a
 gloo side group (host memory, no GPU sync) and pass the global batch size to the loss.
 """
+import contextlib
+import json
 import os
+import sys
+import threading
+from datetime import timedelta
 
 import torch
 import torch.distributed as dist
 
 
+def dist_timeout_s():
+    """Bound on rendezvous and on every collective of the process group (DBX_DIST_TIMEOUT_S, default 120 s: the torch default of ten
+    minutes turns a mis-configured first multi-GPU run into a silent hang)."""
+    return float(os.environ.get('DBX_DIST_TIMEOUT_S', '120'))
+
+
+def rccl_info():
+    """What a failure report needs to say about the collective set-up (also part of the bench line)."""
+    env = {k: v for k, v in os.environ.items()
+           if k.startswith(('NCCL_', 'RCCL_', 'HSA_ENABLE_IPC', 'MASTER_', 'DBX_DIST_')) or k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    info = {'backend': dist.get_backend() if dist.is_initialized() else None,
+            'world': dist.get_world_size() if dist.is_initialized() else int(os.environ.get('WORLD_SIZE', '1')),
+            'timeout_s': dist_timeout_s(), 'env': env,
+            'gpus_visible': torch.cuda.device_count() if torch.cuda.is_available() else 0}
+    return info
+
+
+def report_failure(what, exc=None, rank=None):
+    """ONE parsable line instead of a hang or a bare traceback: rank 0 prints it on stdout (where the bench line would have been), the
+    other ranks on stderr."""
+    rank = int(os.environ.get('RANK', '0')) if rank is None else rank
+    line = json.dumps({'error': what + ((': %s: %s' % (type(exc).__name__, str(exc)[:600])) if exc is not None else ''),
+                       'rank': rank, 'rccl': rccl_info()})
+    print(line, file=sys.stdout if rank == 0 else sys.stderr, flush=True)
+
+
+@contextlib.contextmanager
+def watchdog(seconds, what, rank=None):
+    """A collective that never completes cannot be interrupted from Python: when `seconds` pass inside the block, report and leave the
+    process (exit code 3) so that the launcher tears the job down."""
+    def expire():
+        report_failure('%s did not complete within %.0f s' % (what, seconds), rank=rank)
+        os._exit(3)
+    t = threading.Timer(seconds, expire)
+    t.daemon = True
+    t.start()
+    try:
+        yield
+    finally:
+        t.cancel()
+
+
+def preflight(dev):
+    """First collective of the job on the data path's backend, under the watchdog: every rank contributes rank + 1."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    world, rank = dist.get_world_size(), dist.get_rank()
+    with watchdog(dist_timeout_s(), 'first all-reduce (%s, world %d)' % (dist.get_backend(), world), rank):
+        t = torch.full((1024,), float(rank + 1), device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        dist.all_reduce(t)
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        want = world * (world + 1) / 2.0
+        if float(t[0]) != want or float(t[-1]) != want:
+            raise RuntimeError('first all-reduce returned %r, expected %r' % (float(t[0]), want))
+
+
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank).
+    Rendezvous and collectives are bounded by dist_timeout_s()."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -26,7 +89,7 @@ def init_from_env(backend=None):
             backend = os.environ.get('DBX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timedelta(seconds=dist_timeout_s()))
     return rank, world, local
 
 

@@ -39,3 +39,43 @@ def test_bench_two_ranks_on_one_gpu_gloo():
                {'DBX_DIST_BACKEND': 'gloo'}, 1200)
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 8 and out['value'] > 0
     assert out['roofline']['kernel'] and 0 < out['roofline']['frac'] < 1
+
+
+def _run_expect_failure(args, env_extra, timeout):
+    import time
+    env = dict(os.environ, **env_extra)
+    env.pop('WORLD_SIZE', None); env.pop('RANK', None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    dt = time.time() - t0
+    assert r.returncode != 0, r.stdout[-2000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    errs = [l for l in lines if 'error' in l]
+    assert errs, 'no parsable failure line:\n' + r.stdout[-2000:] + r.stderr[-3000:]
+    assert not any('value' in l for l in lines)         # no bench line next to a failure line
+    return errs[0], dt
+
+
+def test_bench_failed_collective_setup_reports_one_json_line():
+    """The N > 1 path must never hang or die with only a traceback: here the RCCL backend is asked for on a box where it cannot
+    come up (no GPU: the process group constructor refuses) -- rank 0 prints {"error": ..., "rccl": {...}} and the job exits non-zero."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('CPU-only variant (the GPU box runs test_bench_two_ranks_nccl_on_one_gpu_fails_fast)')
+    err, dt = _run_expect_failure(['--gpus', '2', '--dry-run'], {'DBX_DIST_BACKEND': 'nccl', 'DBX_DIST_TIMEOUT_S': '30'}, 300)
+    assert err['rccl']['world'] == 2 and err['rccl']['timeout_s'] == 30.0 and 'DBX_DIST_BACKEND' in err['rccl']['env']
+    assert dt < 150
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_nccl_on_one_gpu_fails_fast():
+    """Two RCCL ranks on ONE GPU cannot form a communicator (duplicate device): the first collective fails or stalls -- the bounded
+    process-group timeout / the watchdog around the first all-reduce turn that into one JSON failure line within the bound, not the
+    ten-minute default hang.  (The first real N > 1 RCCL run happens on the driver's multi-GPU box with nobody watching.)"""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip('needs exactly one visible GPU')
+    err, dt = _run_expect_failure(['--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '2', '--no-cpu-baseline', '--no-inference'],
+                                  {'DBX_DIST_BACKEND': 'nccl', 'DBX_DIST_TIMEOUT_S': '60'}, 400)
+    assert err['rccl']['world'] == 2 and err['rccl']['gpus_visible'] == 1
+    assert dt < 150, dt
