@@ -399,8 +399,10 @@ def run(args):
             fl = sum(v['flops'] for k, v in fam.items() if pred(k))
             return {'tflops': round(fl / (us * 1e-6) / 1e12, 1), 'frac': round(fl / (us * 1e-6) / 1e12 / peak, 4),
                     'us_per_step': round(us / 3, 1)} if us > 0 else None
+        def is3(k):          # a 3x3 forward / data-gradient family (the ws / p8 templates also serve 1x1 GEMMs: <T,WM,1,..> / <T,1>)
+            return k.startswith('conv3x3_') and not re.match(r'conv3x3_ws_kernel<\w+,\d+,1,', k) and not re.match(r'conv3x3_p8_kernel<\w+,1>', k)
         # the dominant forward / data-gradient conv family on its own (round 1's dominant kernel was one: continuity of the series)
-        convs = {k: v for k, v in fam.items() if k.startswith('conv3x3_') and not re.match(r'conv3x3_ws_kernel<\w+,\d+,1,', k)}
+        convs = {k: v for k, v in fam.items() if is3(k)}
         if convs:
             dc = max(convs, key=lambda k: convs[k]['us'])
             ac = convs[dc]['flops'] / (convs[dc]['us'] * 1e-6) / 1e12
@@ -408,8 +410,6 @@ def run(args):
                                      'launches_per_step': convs[dc]['launches'] // 3, 'us_per_step': round(convs[dc]['us'] / 3, 1),
                                      'traffic': pmc_traffic(dc)}
         # (the ws kernel template serves 3x3 layers <T,WM,3,EPIK> and the 1x1 head GEMMs <T,1,1,EPIK>: only the former belong here)
-        def is3(k):
-            return k.startswith('conv3x3_') and not re.match(r'conv3x3_ws_kernel<\w+,\d+,1,', k)
         roof['stack_3x3'] = {'fwd_dgrad': agg(is3),
                              'with_wgrad': agg(lambda k: is3(k) or k.startswith(('wgrad_all9', 'wgrad_row3', 'wgrad3x3')))}
         out = {

@@ -16,7 +16,7 @@ ESIZE = {F16: 2, BF16: 2, F32: 4}
 
 EPI_BIAS, EPI_RELU, EPI_GATE, EPI_DROPMASK, EPI_ACCUM, EPI_F32_NCHW, EPI_DROPHASH = 1, 2, 4, 8, 16, 32, 64
 CONV_WFRAG = 128          # w_packed is in MFMA-fragment order (pack modes 4/5)
-K_IGEMM, K_DMA, K_BAND, K_C64, K_C8, K_WS = 1, 2, 3, 4, 5, 6
+K_IGEMM, K_DMA, K_BAND, K_C64, K_C8, K_WS, K_P8 = 1, 2, 3, 4, 5, 6, 7
 
 
 class View(C.Structure):

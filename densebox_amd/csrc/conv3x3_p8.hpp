@@ -1,0 +1,246 @@
+// Round 5: implicit-GEMM convolution (3x3 / pad 1 on congruent frames, or 1x1) on the 8-phase MFMA core (mma8p.hpp).
+// Included by conv_igemm.hip (needs ConvArgs, gate_packed16).  Forward and -- with flipped / transposed packed weights -- data gradient
+// of the wide backbone layers (couts a multiple of 256, input channels a multiple of 64, 16-bit types), plain packed weights
+// [cout][tap][cin] (dbx_pack_weight modes 0 / 1: no fragment-order image).
+//
+//   GEMM view: m = output pixel (COMPACT index p = (n H + y) W + x: no halo positions are computed), n = cout, K = (64-channel chunk, tap)
+//   with the taps fastest (the nine taps of a chunk re-read the same pixel rows: L1 / L2 hits).  A K tile of the "A" matrix is 256
+//   pixels x 128 bytes at frame offset tap(ky, kx) -- each lane's LDS-DMA source is its pixel's frame address (one 32-bit register per
+//   piece, computed once per output tile: two divisions), the tap is a scalar offset: no im2col, no bounds checks (zero frame).
+//   The "B" matrix is the packed weight as it lies in memory.
+//
+//   Persistent workgroups (one per CU) with BALANCED tile heights: a tile is 8 or 7 units of 32 pixels (p8::ktiles<.., MI1 = 4 / 3>), their
+//   number rounded up to whole rounds of CUs (ws_schedule) -- 450 tiles of 256 pixels on 256 CUs would be two rounds at 88 %.  The load
+//   stream never stops at a tile seam: the last two K tiles of a tile stage the first seven half-tiles of the NEXT one, the epilogue
+//   (bias, ReLU | ReLU-gate, 16-byte NHWC stores; gate chunks of eight fragments requested ahead of the first store) runs between two
+//   phases while those loads fly, and stores are younger than the loads the next counted wait covers.
+#pragma once
+#include "mma8p.hpp"
+
+struct P8Args {
+    int mt;              // pixel tiles
+    int base, extra;     // tile t covers base + (t < extra) units of 32 pixels, starting at unit t base + min(t, extra)
+    int items;           // mt * ntile_n
+    int nkt;             // K tiles: taps * cin / 64 (even)
+    int HW, W;           // output pixels per image / per row
+    float inv_HW, inv_W;
+};
+
+template <typename T, int KS, int FLAGS = p8::FL_STAGGER>
+__global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, const P8Args t) {
+    constexpr int ES = sizeof(T);
+    static_assert(ES == 2, "16-bit types");
+    constexpr int NTAPS = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const p8::Lanes<16> L = p8::lanes<16>(smem);
+    const int lane = L.lane, wave = L.wave;
+    const int pix_bytes = a.x_ld * ES;
+    const int nkt = t.nkt;
+    const int cin_bytes = a.cpt * 16;
+
+    // ---- persistent schedule (as conv3x3_ws_kernel): workgroup g runs on XCD g % 8; with two or four cout tiles an XCD keeps to ONE
+    // of them for the whole launch (its workgroups stream the same weights through its L2 in step), otherwise an XCD works on
+    // neighbouring pixel tiles
+    const int G = gridDim.x;
+    const bool by_xcd = (G & 7) == 0 && (a.ntile_n == 2 || a.ntile_n == 4);
+    int item;
+    if (by_xcd) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        item = ((xcd / a.ntile_n) * (G >> 3) + j) * a.ntile_n + xcd % a.ntile_n;
+    } else {
+        item = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    }
+    if (item >= t.items) return;
+
+    struct Tile { int p0, nf, n0; };
+    auto tile_of = [&](int it) {
+        Tile r;
+        const int tm = it / a.ntile_n, tn = it - tm * a.ntile_n;
+        const int u0 = tm * t.base + (tm < t.extra ? tm : t.extra);
+        r.nf = t.base + (tm < t.extra ? 1 : 0);
+        r.p0 = u0 * 32;
+        r.n0 = tn * 256;
+        return r;
+    };
+    // pixel index -> (image, row, column): float estimate + one correction step (exact for p < 2^24)
+    auto split = [&](int p, int& n, int& oy, int& ox) {
+        n = (int)(((float)p + 0.5f) * t.inv_HW);
+        int r = p - n * t.HW;
+        if (r < 0) { --n; r += t.HW; }
+        if (r >= t.HW) { ++n; r -= t.HW; }
+        oy = (int)(((float)r + 0.5f) * t.inv_W);
+        ox = r - oy * t.W;
+        if (ox < 0) { --oy; ox += t.W; }
+        if (ox >= t.W) { ++oy; ox -= t.W; }
+    };
+    // tile row (half mh, row r of the half's 128 LDS rows) -> pixel index offset from p0; 7-unit tiles use rows 0..47 of each wave's 64 of half 1
+    auto row_index = [&](int nf, int mh, int r) { return mh == 0 ? r : (nf == 8 ? 128 + r : 128 + (r >> 6) * 48 + ((r & 63) < 48 ? (r & 63) : 0)); };
+    // ---- LDS-DMA source offsets of a tile's pixel rows: this lane loads LDS row 64 j + 8 wave + (lane >> 3) of each half-tile
+    const unsigned chunk16 = p8::src_chunk(wave, lane) << 4;
+    auto a_offsets = [&](const Tile& tl, unsigned (&vo)[2][2]) {
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int p = tl.p0 + row_index(tl.nf, mh, j * 64 + wave * 8 + (lane >> 3));
+                p = p < a.M ? p : a.M - 1;                          // rows past the end: any valid pixel (their results are dropped)
+                int n, oy, ox;
+                split(p, n, oy, ox);
+                vo[mh][j] = (unsigned)((n * a.x_hp + oy + a.x_org) * a.x_wp + ox + a.x_org) * (unsigned)pix_bytes + chunk16;
+            }
+    };
+    const unsigned voB = (unsigned)((wave * 8 + (lane >> 3)) * a.ktot_bytes) + chunk16;
+
+    Tile cur = tile_of(item), nxt = cur;
+    unsigned vcur[2][2], vnxt[2][2];
+    a_offsets(cur, vcur);
+#pragma unroll
+    for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vnxt[mh][j] = vcur[mh][j];
+
+    // K tile kt of the stream: kt >= nkt is K tile kt - nkt of the NEXT output tile
+    auto k_split = [&](int kt, bool& nx, int& chunk, int& tap) {
+        nx = kt >= nkt;
+        const int k = nx ? kt - nkt : kt;
+        if constexpr (NTAPS == 9) { chunk = (k * 7282) >> 16; tap = k - chunk * 9; }       // k / 9 for k < 7000
+        else { chunk = k; tap = 0; }
+    };
+    auto stA = [&](int kt, int mh, unsigned dst) {
+        bool nx; int chunk, tap;
+        k_split(kt, nx, chunk, tap);
+        int toff = 0;
+        if constexpr (NTAPS == 9) { const int ky = (tap * 11) >> 5, kx = tap - 3 * ky; toff = (ky * a.x_wp + kx) * pix_bytes; }
+        const char* b = a.x + toff + chunk * 128;
+        p8::glds(b, nx ? vnxt[mh][0] : vcur[mh][0], dst);
+        p8::glds(b, nx ? vnxt[mh][1] : vcur[mh][1], dst + 8192);
+    };
+    auto stB = [&](int kt, int nh, unsigned dst) {
+        bool nx; int chunk, tap;
+        k_split(kt, nx, chunk, tap);
+        const char* b = a.w + (size_t)((nx ? nxt.n0 : cur.n0) + nh * 128) * a.ktot_bytes + tap * cin_bytes + chunk * 128;
+        p8::glds(b, voB, dst);
+        p8::glds(b + (size_t)64 * a.ktot_bytes, voB, dst + 8192);
+    };
+
+    // ---- bias of this lane's couts: n = n0 + 128 nh + 32 wc + 16 ni + 4 (lane >> 4) + 0..3; reloaded when the cout tile changes
+    const int epi = a.epi;
+    const int g4 = lane >> 4;
+    f32x4 bias[2][2];
+    int bias_n0 = -1;
+
+    p8::prologue<16>(L, stA, stB);
+    p8::start<FLAGS>(L);
+    p8::Acc<16> acc;
+    for (;;) {
+        const int nxt_item = item + G;
+        const bool more = nxt_item < t.items;
+        if (more) { nxt = tile_of(nxt_item); a_offsets(nxt, vnxt); }          // last tile: the stream re-fetches its own start (never read)
+        p8::zero<16>(acc);
+        if (cur.n0 != bias_n0) {
+            bias_n0 = cur.n0;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    bias[nh][ni] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cur.n0 + nh * 128 + L.wc * 32 + ni * 16 + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        auto body = [&](auto MI1_) {
+            constexpr int MI1 = decltype(MI1_)::value;
+            p8::ktiles<T, 16, FLAGS, MI1>(acc, L, nkt, stA, stB);
+            // ---- epilogue (compiler-scheduled; no LDS).  Row m of half mh -> output pixel; chunk = eight consecutive couts of it
+            const int pend = cur.p0 + cur.nf * 32 < a.M ? cur.p0 + cur.nf * 32 : a.M;
+            T* const ybase = (T*)a.y + cur.n0;
+            const T* const gbase = (const T*)a.gate + cur.n0;
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+                constexpr int NIH = 4;
+                size_t yo[NIH], go[NIH];
+                bool ok[NIH];
+                u32x4 gt[NIH][2];
+#pragma unroll
+                for (int mi = 0; mi < NIH; ++mi) {
+                    if (mh == 1 && mi >= MI1) continue;
+                    const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + (lane & 15));
+                    ok[mi] = p < pend;
+                    int n, oy, ox;
+                    split(ok[mi] ? p : cur.p0, n, oy, ox);
+                    yo[mi] = (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (size_t)a.y_ld;
+                    go[mi] = (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld;
+                    // the gate chunks of the whole half first: a load behind a store is issued behind it, and one wave group has
+                    // nothing else to hide a latency under
+                    if (epi & DBX_EPI_GATE) {
+                        const int nc = L.wc * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh) gt[mi][nh] = *(const u32x4*)(gbase + go[mi] + nh * 128 + nc);
+                    }
+                }
+#pragma unroll
+                for (int mi = 0; mi < NIH; ++mi) {
+                    if (mh == 1 && mi >= MI1) continue;
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        f32x4 v0 = acc.v[mh][nh][mi][0] + bias[nh][0], v1 = acc.v[mh][nh][mi][1] + bias[nh][1];
+                        if (epi & DBX_EPI_RELU) {
+                            v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                            v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+                        }
+                        u32x4 o = pair_exchange<T>(v0, v1);                  // all lanes: eight consecutive couts at pair_cout_off
+                        if (epi & DBX_EPI_GATE) o = gate_packed16(o, gt[mi][nh]);
+                        if (ok[mi]) *(u32x4*)(ybase + yo[mi] + nh * 128 + L.wc * 32 + pair_cout_off(g4, 0)) = o;
+                    }
+                }
+            }
+        };
+        if (cur.nf == 8) body(pipe::IC<4>{});
+        else body(pipe::IC<3>{});
+        if (!more) break;
+        item = nxt_item;
+        cur = nxt;
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) vcur[mh][j] = vnxt[mh][j];
+    }
+    p8::finish<FLAGS>(L);
+}
+
+// tile schedule: units of 32 pixels, tiles of 7 or 8 units, their number rounded up to fill whole rounds of CUs
+static inline bool p8_schedule(long long M, int ntile_n, int ncu, P8Args& t) {
+    const long long units = (M + 31) / 32;
+    long long mt = (units + 7) / 8;
+    const long long wgs = mt * ntile_n;
+    if (wgs > ncu) {
+        const long long up = (wgs + ncu - 1) / ncu * ncu / ntile_n;     // tiles that fill the last round
+        if (up > mt && units / up >= 7) mt = up;
+    }
+    t.mt = (int)mt; t.base = (int)(units / mt); t.extra = (int)(units % mt);
+    t.items = (int)(mt * ntile_n);
+    return t.base == 8 ? t.extra == 0 : t.base == 7;                    // the kernel has 7- and 8-unit tiles
+}
+
+template <typename T, int KS>
+static int launch_conv_p8(const ConvArgs& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        static DbxDevOnce attr_once; int attr_dev = 0;
+        if (attr_once.pending(&attr_dev)) {
+            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_p8_kernel<T, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, p8::LDS_BYTES));
+            attr_once.mark(attr_dev);
+        }
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            DBX_HIP(hipGetDevice(&dev));
+            DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        P8Args t;
+        DBX_REQUIRE(p8_schedule(a.M, a.ntile_n, ncu, t), "conv p8: no 7/8-unit tile schedule for %d pixels", a.M);
+        t.nkt = KS * KS * (a.cpt / 8);
+        t.HW = a.HoWo; t.W = a.Wo;
+        t.inv_HW = 1.0f / (float)a.HoWo; t.inv_W = 1.0f / (float)a.Wo;
+        const int grid = t.items < ncu ? t.items : ncu;
+        hipLaunchKernelGGL((conv3x3_p8_kernel<T, KS>), dim3(grid), dim3(512), p8::LDS_BYTES, s, a, t);
+        DBX_LAUNCH_CHECK();
+    }
+    return DBX_OK;
+}

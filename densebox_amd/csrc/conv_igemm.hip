@@ -1433,6 +1433,7 @@ static int launch_conv_c64(const ConvArgs& a, int n, int h, int w, hipStream_t s
 }
 
 #include "conv3x3_c64p.hpp"
+#include "conv3x3_p8.hpp"
 #include "heads_gen.hpp"
 
 static int ws_level() {              // DBX_WS=0 keeps the LDS band kernels on every layer, 2 plans ws wherever it can run (A/B testing)
@@ -1555,6 +1556,38 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     }
     DBX_REQUIRE(a.M > 0 && (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < (int64_t)1 << 40, "conv: empty or oversized input");
 
+    // Round 5: the wide 3x3 layers (couts a multiple of 256, >= 128 input channels, plain / ReLU / ReLU-gate epilogue) on the 8-phase
+    // MFMA core (conv3x3_p8.hpp; plain packed weights).  DBX_P8=0: off (the ws / band kernels of rounds 2-4 keep them); 2: every eligible problem.
+    {
+        static int p8_level = -1;
+        if (p8_level < 0) { const char* e = getenv("DBX_P8"); p8_level = e ? atoi(e) : 1; }
+        const bool k3 = d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1;
+        const bool k1 = d->kh == 1 && d->kw == 1 && d->cpad == 0;
+        const int kk = d->epilogue & ~(DBX_EPI_BIAS | DBX_CONV_WFRAG);
+        const int taps = d->kh * d->kw;
+        bool p8_ok = p8_level != 0 && !smallc && sizeof(T) == 2 && (k3 || k1) && !(d->epilogue & DBX_CONV_WFRAG) && !y2 && !pool_idx && !w2_frag &&
+                     (kk == 0 || kk == DBX_EPI_RELU || kk == DBX_EPI_GATE) && d->cin_pad % 64 == 0 && (taps * (d->cin_pad / 64)) % 2 == 0 &&
+                     taps * (d->cin_pad / 64) >= 4 && taps * (d->cin_pad / 64) < 7000 && d->cout_pad % 256 == 0 && y->c == d->cout_pad &&
+                     (y->c_off * ES) % 16 == 0 && (y->ld * ES) % 16 == 0 && a.M < (1 << 24) &&
+                     (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < ((int64_t)1 << 32) && (int64_t)64 * a.ktot_bytes < ((int64_t)1 << 31);
+        if (p8_ok && (d->epilogue & DBX_EPI_GATE) && gate) p8_ok = (gate->c_off * ES) % 16 == 0 && (gate->ld * ES) % 16 == 0;
+        if (p8_ok) {
+            static int ncu = 0;
+            if (!ncu) { int dev = 0; DBX_HIP(hipGetDevice(&dev)); DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)); }
+            P8Args ts;
+            p8_ok = p8_schedule(a.M, y->c / 256, ncu, ts) && ts.items >= (ncu * 3) / 4;                 // 7- / 8-unit tiles that fill the chip
+        }
+        const bool p8_pref = k3 && d->cin_pad >= 128;
+        if (p8_ok && (p8_pref || p8_level >= 2)) {
+            a.ntile_n = y->c / 256;
+            if (plan) {
+                plan->kernel = DBX_K_P8; plan->tile_m = 256; plan->tile_n = 256; plan->w_frag = 0;
+                snprintf(plan->name, sizeof plan->name, "conv3x3_p8_kernel<%s,%d>", tname, k3 ? 3 : 1);
+                return DBX_OK;
+            }
+            return k3 ? launch_conv_p8<T, 3>(a, s) : launch_conv_p8<T, 1>(a, s);
+        }
+    }
     // Wide 16-bit layers with enough tiles to fill the chip: register-streamed weights (conv3x3_ws.hpp) -- the 3x3 / pad 1
     // backbone layers on congruent frames and the 1x1 head GEMMs (768 -> 512 heads forward; its split-destination data
     // gradient).  The kernel needs the weights in fragment order: a launch takes it iff the caller says so (DBX_CONV_WFRAG);

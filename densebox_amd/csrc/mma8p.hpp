@@ -118,31 +118,51 @@ template <int MF> __device__ __forceinline__ Lanes<MF> lanes(const char* smem) {
     return L;
 }
 
-// The K loop.  nkt (even, >= 2) K tiles.  srcA(kt, mh, j) / srcB(kt, nh, j): wave-uniform byte pointer to row 128 h + 64 j of the
-// workgroup's tile at K tile kt (j = 0, 1: the two pieces a wave loads per half-tile); voffA[mh][j] / voffB: the lane's byte offset from
-// it = (8 wave + (lane >> 3)) * row stride + (src_chunk << 4) (+ whatever the caller's row map adds, e.g. an image-seam skip).
-// Tiles past the end are clamped to the last one (their loads land in buffers nobody reads any more): the counted waits stay uniform.
-template <typename T, int MF, int FLAGS, typename FA, typename FB>
-__device__ __forceinline__ void kloop(Acc<MF>& acc, const Lanes<MF>& L, int nkt, const unsigned (&voffA)[2][2], const unsigned (&voffB)[2][2], FA srcA, FB srcB) {
-    constexpr bool PRIO = FLAGS & FL_PRIO, STAG = FLAGS & FL_STAGGER, SAFE = FLAGS & FL_SAFE;
+// The phase program.  A "stage" functor issues the wave's two LDS-DMA pieces of one half-tile: stA(kt, mh, dst) / stB(kt, nh, dst) with dst =
+// this wave's LDS destination of piece 0 (piece 1 goes to dst + 8192); kt may run past the tile's nkt by up to 2: the caller decides
+// what the stream carries there (the next tile of a persistent workgroup, or a clamped re-load nobody reads) -- it must issue
+// exactly two LDS-DMA per call in any case, the counted waits rely on it.
+//
+//   prologue(L, stA, stB)         K tile 0 and three half-tiles of K tile 1 go out (first tile of a workgroup only)
+//   start<FLAGS>(L)               K tile 0 has landed for everybody; the wave groups go one barrier apart
+//   ktiles<..>(acc, L, nkt, ..)   the 4 nkt phases of one output tile (nkt even); may be called tile after tile -- the seam between
+//                                 two tiles is an ordinary K-tile transition of the stream (an epilogue in between touches no LDS)
+//   finish<FLAGS>(L)              the groups meet again, nothing is in flight
+template <int MF, typename SA, typename SB>
+__device__ __forceinline__ void prologue(const Lanes<MF>& L, SA stA, SB stB) {
+    stB(0, 0, L.dst + 65536); stA(0, 0, L.dst); stB(0, 1, L.dst + 65536 + 16384); stA(0, 1, L.dst + 16384);
+    stB(1, 0, L.dst + 65536 + 32768); stA(1, 0, L.dst + 32768); stB(1, 1, L.dst + 65536 + 49152);
+}
+template <int FLAGS, int MF>
+__device__ __forceinline__ void start(const Lanes<MF>& L) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    barrier();
+    if ((FLAGS & FL_STAGGER) && L.wr == 1) barrier();
+}
+template <int FLAGS, int MF>
+__device__ __forceinline__ void finish(const Lanes<MF>& L) {
+    if ((FLAGS & FL_STAGGER) && L.wr == 0) barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // over-run loads of the stream: nothing lands in the LDS behind this point
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// MI1: 16-row fragments per wave in the SECOND m half (16x16x32 only): 4 = 256-row tile, 3 = 224 rows (LDS rows 48..63 of each wave's
+// 64 of half-tile A[1] are loaded and ignored): persistent workgroups balance their tile heights with it.
+template <typename T, int MF, int FLAGS, int MI1 = (MF == 16 ? 4 : 2), typename SA, typename SB>
+__device__ __forceinline__ void ktiles(Acc<MF>& acc, const Lanes<MF>& L, int nkt, SA stA, SB stB) {
+    constexpr bool PRIO = FLAGS & FL_PRIO, SAFE = FLAGS & FL_SAFE;
+    static_assert(MF == 16 ? (MI1 >= 2 && MI1 <= 4) : MI1 == 2, "tile height");
     u32x4 af[8], bf[2][4];
-    auto stageA = [&](int kt, int mh, int d) {
-        kt = kt < nkt ? kt : nkt - 1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds(srcA(kt, mh, j), voffA[mh][j], L.dst + (d * 2 + mh) * 16384 + j * 8192);
-    };
-    auto stageB = [&](int kt, int nh, int d) {
-        kt = kt < nkt ? kt : nkt - 1;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) glds(srcB(kt, nh, j), voffB[nh][j], L.dst + 65536 + (d * 2 + nh) * 16384 + j * 8192);
-    };
     auto readA = [&](auto D_, auto H_) {
         constexpr int d = decltype(D_)::value, mh = decltype(H_)::value, base = (d * 2 + mh) * 16384;
+        constexpr int NI = mh == 0 ? 4 : MI1;
         if constexpr (MF == 16) {
             lds_read<base + 0 * 2048>(af[0], L.ra[0]); lds_read<base + 1 * 2048>(af[1], L.ra[0]);
-            lds_read<base + 2 * 2048>(af[2], L.ra[0]); lds_read<base + 3 * 2048>(af[3], L.ra[0]);
+            if constexpr (NI > 2) lds_read<base + 2 * 2048>(af[2], L.ra[0]);
+            if constexpr (NI > 3) lds_read<base + 3 * 2048>(af[3], L.ra[0]);
             lds_read<base + 0 * 2048>(af[4], L.ra[1]); lds_read<base + 1 * 2048>(af[5], L.ra[1]);
-            lds_read<base + 2 * 2048>(af[6], L.ra[1]); lds_read<base + 3 * 2048>(af[7], L.ra[1]);
+            if constexpr (NI > 2) lds_read<base + 2 * 2048>(af[6], L.ra[1]);
+            if constexpr (NI > 3) lds_read<base + 3 * 2048>(af[7], L.ra[1]);
         } else {
             lds_read<base>(af[0], L.ra[0]); lds_read<base + 4096>(af[1], L.ra[0]);
             lds_read<base>(af[2], L.ra[1]); lds_read<base + 4096>(af[3], L.ra[1]);
@@ -160,14 +180,15 @@ __device__ __forceinline__ void kloop(Acc<MF>& acc, const Lanes<MF>& L, int nkt,
             lds_read<base>(bf[nh][2], L.rb[2]); lds_read<base>(bf[nh][3], L.rb[3]);
         }
     };
-    // 16 (8) MFMAs of quadrant (mh, nh); af / bf index = K sub-step major
+    // the MFMAs of quadrant (mh, nh); af / bf index = K sub-step major
     auto cluster = [&](auto MH_, auto NH_) {
         constexpr int mh = decltype(MH_)::value, nh = decltype(NH_)::value;
         if constexpr (MF == 16) {
+            constexpr int NI = mh == 0 ? 4 : MI1;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                for (int mi = 0; mi < NI; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) Mma16<T>::run(bf[nh][kk * 2 + ni], af[kk * 4 + mi], acc.v[mh][nh][mi][ni]);
         } else {
@@ -184,10 +205,10 @@ __device__ __forceinline__ void kloop(Acc<MF>& acc, const Lanes<MF>& L, int nkt,
         if constexpr (P == 2) readB(IC<d>{}, IC<1>{});
         if constexpr (P == 3) readA(IC<d>{}, IC<1>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (P == 1) stageA(kt + 1, 1, d ^ 1);
-        if constexpr (P == 2) stageB(kt + 2, 0, d);
-        if constexpr (P == 3) stageA(kt + 2, 0, d);
-        if constexpr (P == 4) stageB(kt + 2, 1, d);
+        if constexpr (P == 1) stA(kt + 1, 1, L.dst + ((d ^ 1) * 2 + 1) * 16384);
+        if constexpr (P == 2) stB(kt + 2, 0, L.dst + 65536 + (d * 2 + 0) * 16384);
+        if constexpr (P == 3) stA(kt + 2, 0, L.dst + (d * 2 + 0) * 16384);
+        if constexpr (P == 4) stB(kt + 2, 1, L.dst + 65536 + (d * 2 + 1) * 16384);
         if constexpr (SAFE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else if constexpr (P == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if constexpr (P == 1) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
@@ -203,20 +224,11 @@ __device__ __forceinline__ void kloop(Acc<MF>& acc, const Lanes<MF>& L, int nkt,
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         barrier();
     };
-    // ---- prologue: K tile 0 complete, three half-tiles of K tile 1 in flight
-    stageB(0, 0, 0); stageA(0, 0, 0); stageB(0, 1, 0); stageA(0, 1, 0);
-    stageB(1, 0, 1); stageA(1, 0, 1); stageB(1, 1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    barrier();
-    if (STAG && L.wr == 1) barrier();
     for (int kt = 0; kt < nkt; kt += 2) {
         using pipe::IC;
         phase(IC<1>{}, IC<0>{}, kt); phase(IC<2>{}, IC<0>{}, kt); phase(IC<3>{}, IC<0>{}, kt); phase(IC<4>{}, IC<0>{}, kt);
         phase(IC<1>{}, IC<1>{}, kt + 1); phase(IC<2>{}, IC<1>{}, kt + 1); phase(IC<3>{}, IC<1>{}, kt + 1); phase(IC<4>{}, IC<1>{}, kt + 1);
     }
-    if (STAG && L.wr == 0) barrier();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped over-run loads: nothing lands in the LDS behind this point
-    __builtin_amdgcn_sched_barrier(0);
 }
 
 }  // namespace p8
@@ -225,7 +237,7 @@ namespace p8 {
 // Epilogue helper: hands every (m row, 8 consecutive n) 16-byte chunk of the wave's accumulators to `f(mh, nh, m_in_half, n_in_half, chunk)`
 // with m_in_half = 64 wr + .., n_in_half = 32 wc + .. (rounded to T; fragment pairs exchanged across lane rows / halves so that a
 // lane owns eight consecutive n).  `fin(mh, nh, n_in_half, v)` may modify the four fp32 values n_in_half .. +3 first (bias, ReLU).
-template <typename T, int MF, typename FIN, typename F>
+template <typename T, int MF, int MI1 = (MF == 16 ? 4 : 2), typename FIN, typename F>
 __device__ __forceinline__ void for_chunks(Acc<MF>& acc, const Lanes<MF>& L, FIN fin, F f) {
     if constexpr (MF == 16) {
         const int l15 = L.lane & 15, g = L.lane >> 4;
@@ -235,6 +247,7 @@ __device__ __forceinline__ void for_chunks(Acc<MF>& acc, const Lanes<MF>& L, FIN
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
+                    if (mh == 1 && mi >= MI1) continue;
                     f32x4 v0 = acc.v[mh][nh][mi][0], v1 = acc.v[mh][nh][mi][1];
                     fin(mh, nh, L.wc * 32 + 4 * g, v0);
                     fin(mh, nh, L.wc * 32 + 16 + 4 * g, v1);

@@ -95,7 +95,7 @@ int dbx_conv_forward(const dbx_conv_desc* d, const dbx_view* x, const void* w_pa
 /* Which kernel dbx_conv_forward would run for (d, x, y), and the weight layout it wants.  The caller packs the weights
  * accordingly (w_frag != 0: dbx_pack_weight mode 4 (forward) / 5 (dgrad) and DBX_CONV_WFRAG in d->epilogue; else modes 0 / 1).
  * `name` is the kernel family and tile as it appears in a rocprofv3 trace (bench.py labels its roofline with it). */
-enum dbx_conv_kernel { DBX_K_IGEMM = 1, DBX_K_DMA = 2, DBX_K_BAND = 3, DBX_K_C64 = 4, DBX_K_C8 = 5, DBX_K_WS = 6 };
+enum dbx_conv_kernel { DBX_K_IGEMM = 1, DBX_K_DMA = 2, DBX_K_BAND = 3, DBX_K_C64 = 4, DBX_K_C8 = 5, DBX_K_WS = 6, DBX_K_P8 = 7 };
 typedef struct dbx_conv_plan_t {
     int32_t kernel;        /* dbx_conv_kernel */
     int32_t tile_m, tile_n;

@@ -16,7 +16,8 @@ def framed(n, h, c, pad=1):
 N = 64
 for name, H, ci, co, epi in [('heads fwd 768->2048 @60', 60, 768, 2048, _lib.EPI_BIAS | _lib.EPI_DROPHASH), ('Wc 256->2048 @60', 60, 256, 2048, _lib.EPI_BIAS | _lib.EPI_DROPHASH),
                              ('Wu 512->2048 @30', 30, 512, 2048, 0), ('dC 2048->256 @60', 60, 2048, 256, 0), ('dA 2048->512 @30', 30, 2048, 512, 0),
-                             ('dgrad 2048->768 @60', 60, 2048, 768, 0)]:
+                             ('dgrad 2048->768 @60', 60, 2048, 768, 0),
+                             ('heads fwd, bias only', 60, 768, 2048, _lib.EPI_BIAS), ('heads fwd 768->512 (one head)', 60, 768, 512, _lib.EPI_BIAS)]:
     fx, x = framed(N, H, ci); fy, y = framed(N, H, co)
     xv = View(C.c_void_p(x.data_ptr()), N, H, H, 1, ci, 0, ci); yv = View(C.c_void_p(y.data_ptr()), N, H, H, 1, co, 0, co)
     d = ConvDesc(dt, 1, 1, 0, ci, co, epi, 0x1234)

@@ -32,14 +32,26 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const GemmArgs a) {
 
     const p8::Lanes<MF> L = p8::lanes<MF>(smem);
     const unsigned vo = (unsigned)((L.wave * 8 + (L.lane >> 3)) * lda) + (p8::src_chunk(L.wave, L.lane) << 4);
-    const unsigned voffA[2][2] = {{vo, vo}, {vo, vo}}, voffB[2][2] = {{vo, vo}, {vo, vo}};
     const char* const Ab = a.A + (size_t)m0 * lda;
     const char* const Bb = a.B + (size_t)n0 * lda;
     p8::Acc<MF> acc;
     p8::zero<MF>(acc);
-    p8::kloop<T, MF, FLAGS>(acc, L, a.K / 64, voffA, voffB,
-        [&](int kt, int mh, int j) { return Ab + (size_t)(mh * 128 + j * 64) * lda + (size_t)kt * 128; },
-        [&](int kt, int nh, int j) { return Bb + (size_t)(nh * 128 + j * 64) * lda + (size_t)kt * 128; });
+    const int nkt = a.K / 64;
+    // tiles past the end of K are clamped to the last one (their loads land in buffers nobody reads any more)
+    auto stA = [&](int kt, int mh, unsigned dst) {
+        kt = kt < nkt ? kt : nkt - 1;
+        const char* b = Ab + (size_t)(mh * 128) * lda + (size_t)kt * 128;
+        p8::glds(b, vo, dst); p8::glds(b + 64 * lda, vo, dst + 8192);
+    };
+    auto stB = [&](int kt, int nh, unsigned dst) {
+        kt = kt < nkt ? kt : nkt - 1;
+        const char* b = Bb + (size_t)(nh * 128) * lda + (size_t)kt * 128;
+        p8::glds(b, vo, dst); p8::glds(b + 64 * lda, vo, dst + 8192);
+    };
+    p8::prologue<MF>(L, stA, stB);
+    p8::start<FLAGS>(L);
+    p8::ktiles<T, MF, FLAGS>(acc, L, nkt, stA, stB);
+    p8::finish<FLAGS>(L);
     T* const C = (T*)a.C;
     p8::for_chunks<T, MF>(acc, L, [](int, int, int, f32x4&) {},
         [&](int mh, int nh, int m, int n, const u32x4& o) { *(u32x4*)(C + (size_t)(m0 + mh * 128 + m) * a.N + n0 + nh * 128 + n) = o; });
