@@ -400,7 +400,7 @@ def run(args):
             return {'tflops': round(fl / (us * 1e-6) / 1e12, 1), 'frac': round(fl / (us * 1e-6) / 1e12 / peak, 4),
                     'us_per_step': round(us / 3, 1)} if us > 0 else None
         def is3(k):          # a 3x3 forward / data-gradient family (the ws / p8 templates also serve 1x1 GEMMs: <T,WM,1,..> / <T,1>)
-            return k.startswith('conv3x3_') and not re.match(r'conv3x3_ws_kernel<\w+,\d+,1,', k) and not re.match(r'conv3x3_p8_kernel<\w+,1>', k)
+            return k.startswith('conv3x3_') and not re.match(r'conv3x3_ws_kernel<\w+,\d+,1,', k) and not re.match(r'conv3x3_p8_kernel<\w+,1[,>]', k)
         # the dominant forward / data-gradient conv family on its own (round 1's dominant kernel was one: continuity of the series)
         convs = {k: v for k, v in fam.items() if is3(k)}
         if convs:

@@ -130,7 +130,7 @@ SIGNATURES = {
     'dbx_nms': (C.c_int, [_VP, _I32, _I32, _D, _VP, _VP, _VP]),
 }
 
-ABI_VERSION = 5          # include/densebox_hip.h DBX_ABI_VERSION this binding was written against
+ABI_VERSION = 6          # include/densebox_hip.h DBX_ABI_VERSION this binding was written against
 _lib = None
 MISSING = []
 

@@ -13,9 +13,18 @@
 //   number rounded up to whole rounds of CUs (ws_schedule) -- 450 tiles of 256 pixels on 256 CUs would be two rounds at 88 %.  The load
 //   stream never stops at a tile seam: the last two K tiles of a tile stage the first seven half-tiles of the NEXT one, the epilogue
 //   (bias, ReLU | ReLU-gate, 16-byte NHWC stores; gate chunks of eight fragments requested ahead of the first store) runs between two
-//   phases while those loads fly, and stores are younger than the loads the next counted wait covers.
+//   phases while those loads fly, and stores are younger than the loads the next counted wait covers.  The two wave groups meet at the
+//   seam (p8::FL_TSYNC) so that their epilogues run side by side on each SIMD instead of one after the other, and part again behind it.
 #pragma once
 #include "mma8p.hpp"
+
+// v if bit B of h is set, else +0 (v_bfe_i32 sign-extends the one-bit field into an AND mask; inline asm: the compiler rewrites the builtin
+// form into v_cmp + v_cndmask)
+template <int B> __device__ __forceinline__ float p8_keep(float v, unsigned h) {
+    int m;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(h), "n"(B));
+    return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
+}
 
 struct P8Args {
     int mt;              // pixel tiles
@@ -26,11 +35,23 @@ struct P8Args {
     float inv_HW, inv_W;
 };
 
-template <typename T, int KS, int FLAGS = p8::FL_STAGGER>
+// EPIK 0: bias and / or ReLU by the arguments' flags; EPIK 2: the ReLU gate of the data gradients, no bias (its own instantiation: the gate
+// chunks of a whole tile are in flight together and want the registers the bias would hold).  EPIK 1 (1x1 only): the heads' forward -- bias + hash dropout
+// (p = 0.5: kept values doubled, the keep bits of dbx_drop_hash32(seed, pixel, channel / 32): the masks the backward kernels regenerate) and,
+// with a.w2f set, the heads' SECOND 1x1 convs (DenseBox.py:158-162: Conv1x1(768 -> 512) -> Dropout -> Conv1x1(512 -> k), k <= 8) on the tile
+// while it is in registers: the 16-byte store chunk of a lane (eight consecutive hidden channels of one pixel, rounded and dropped --
+// exactly what lands in the hidden map) IS the B operand of a v_mfma_f32_16x16x32 (K slots 8 g .. 8 g + 7 of column = pixel) whose A
+// operand is the [k rows][those channels] slice of the head's second weight: a.w2f = plain [64 rows][all hidden channels] image, head i's
+// rows 0 .. k_i - 1 in its 512 columns, zero elsewhere, so a lane's A fragment is ONE 16-byte load.  Two MFMAs per pixel fragment
+// leave a wave's partial sums over its 64 channels in four registers; the four waves of a group (they share the pixels and split the
+// channels) are summed in wave order through 16 KB of LDS behind the stream's buffers and the workgroup stores
+// a.part[cout tile][pixel][8] (fp32) -- heads2_finish_kernel adds a head's two tiles and the bias (as for the ws kernel's EPIK 2).
+template <typename T, int KS, int FLAGS = p8::FL_STAGGER | p8::FL_TSYNC, int EPIK = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, const P8Args t) {
     constexpr int ES = sizeof(T);
     static_assert(ES == 2, "16-bit types");
     constexpr int NTAPS = KS * KS;
+    static_assert(EPIK != 1 || KS == 1, "the heads epilogue belongs to the 1x1 instantiation");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const p8::Lanes<16> L = p8::lanes<16>(smem);
     const int lane = L.lane, wave = L.wave;
@@ -137,60 +158,130 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
         const bool more = nxt_item < t.items;
         if (more) { nxt = tile_of(nxt_item); a_offsets(nxt, vnxt); }          // last tile: the stream re-fetches its own start (never read)
         p8::zero<16>(acc);
-        if (cur.n0 != bias_n0) {
+        if (EPIK != 2 && cur.n0 != bias_n0) {
             bias_n0 = cur.n0;
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    bias[nh][ni] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cur.n0 + nh * 128 + L.wc * 32 + ni * 16 + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    bias[nh][ni] = (EPIK == 1 || (epi & DBX_EPI_BIAS)) ? *(const f32x4*)(a.bias + cur.n0 + nh * 128 + L.wc * 32 + ni * 16 + 4 * g4) * (EPIK == 1 ? 2.f : 1.f)
+                                                                       : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         auto body = [&](auto MI1_) {
             constexpr int MI1 = decltype(MI1_)::value;
+            p8::tile_begin<FLAGS>(L);
             p8::ktiles<T, 16, FLAGS, MI1>(acc, L, nkt, stA, stB);
+            p8::tile_end<FLAGS>(L);
+            if constexpr (EPIK == 1) {
+                // ---- heads forward: 2 (acc + bias) behind the keep bits, rounded, stored; the second convs on the stored chunks
+                const int pend = cur.p0 + cur.nf * 32 < a.M ? cur.p0 + cur.nf * 32 : a.M;
+                T* const ybase = (T*)a.y + cur.n0;
+                const int l15 = lane & 15;
+                const int cl = L.wc * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;            // this lane's eight channels inside the 128-channel half
+                u32x4 w2f[2];
+                if (a.w2f) {
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+                        w2f[nh] = *(const u32x4*)(a.w2f + ((size_t)l15 * (size_t)(a.ntile_n * 256) + cur.n0 + nh * 128 + cl) * ES);
+                }
+                char* const red = smem + p8::LDS_BYTES + L.wr * 16384;
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        if (mh == 1 && mi >= MI1) continue;
+                        const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + l15);
+                        const bool ok = p < pend;
+                        const int pp = ok ? p : cur.p0;
+                        int n, oy, ox;
+                        split(pp, n, oy, ox);
+                        const size_t yo = (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (size_t)a.y_ld;
+                        f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh) {
+                            // one hash covers the wave's 32 channels of this pixel; lane row g holds bits 4 g .. of each 16-channel fragment
+                            const unsigned hs = dbx_drop_hash32(a.drop_seed, (unsigned)pp, (unsigned)(cur.n0 + nh * 128 + L.wc * 32) >> 5) >> (4 * g4);
+                            f32x4 v[2];
+#pragma unroll
+                            for (int ni = 0; ni < 2; ++ni) {
+                                v[ni] = acc.v[mh][nh][mi][ni] * 2.f + bias[nh][ni];
+                            }
+                            // a dropped element is cleared by ANDing with the sign-extended one-bit field of the hash (p8_keep<bit>: the bit
+                            // position is an immediate of v_bfe_i32)
+                            v[0].x = p8_keep<0>(v[0].x, hs); v[0].y = p8_keep<1>(v[0].y, hs); v[0].z = p8_keep<2>(v[0].z, hs); v[0].w = p8_keep<3>(v[0].w, hs);
+                            v[1].x = p8_keep<16>(v[1].x, hs); v[1].y = p8_keep<17>(v[1].y, hs); v[1].z = p8_keep<18>(v[1].z, hs); v[1].w = p8_keep<19>(v[1].w, hs);
+                            const u32x4 o = pair_exchange<T>(v[0], v[1]);
+                            if (a.w2f) p8::Mma16<T>::run(w2f[nh], o, acc2);
+                            if (ok) *(u32x4*)(ybase + yo + nh * 128 + cl) = o;
+                        }
+                        // rows 4 g .. 4 g + 3 of the second convs' outputs for pixel l15: only g < 2 (k <= 8) carries anything
+                        if (a.w2f && g4 < 2) *(f32x4*)(red + ((L.wc * 8 + mh * 4 + mi) * 32 + (lane & 31)) * 16) = acc2;
+                    }
+                if (a.w2f) {
+                    // the group's four waves, summed in wave order; wave wc finishes fragments 2 wc and 2 wc + 1.  The barrier is the
+                    // whole workgroup's (every wave runs the same barrier sequence one phase apart: the stagger is unchanged)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    p8::barrier();
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int f = 2 * L.wc + k, mh = f >> 2, mi = f & 3;
+                        if (mh == 1 && mi >= MI1) continue;
+                        if (lane < 32) {
+                            f32x4 sum = *(const f32x4*)(red + ((0 * 8 + f) * 32 + lane) * 16);
+#pragma unroll
+                            for (int w = 1; w < 4; ++w) sum += *(const f32x4*)(red + ((w * 8 + f) * 32 + lane) * 16);
+                            const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + l15);
+                            if (p < pend) *(f32x4*)(a.part + ((size_t)(cur.n0 >> 8) * a.M + p) * 8 + 4 * (lane >> 4)) = sum;
+                        }
+                    }
+                }
+                return;
+            }
             // ---- epilogue (compiler-scheduled; no LDS).  Row m of half mh -> output pixel; chunk = eight consecutive couts of it
             const int pend = cur.p0 + cur.nf * 32 < a.M ? cur.p0 + cur.nf * 32 : a.M;
             T* const ybase = (T*)a.y + cur.n0;
             const T* const gbase = (const T*)a.gate + cur.n0;
+            const int nc = L.wc * 32 + pair_cout_off(g4, 0);
+            unsigned yo[2][4];                                          // element offsets (the tensors are < 4 GB: checked by the host)
+            bool ok[2][4];
+            u32x4 gt[2][4][2];
+            // addresses of the tile's eight pixel rows, and ALL its gate chunks requested before the first store goes out: a load behind a
+            // store is issued behind it, and the epilogue has nothing else to hide a memory latency under (the operand fragments' 64
+            // registers are free here)
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh) {
-                constexpr int NIH = 4;
-                size_t yo[NIH], go[NIH];
-                bool ok[NIH];
-                u32x4 gt[NIH][2];
+            for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
-                for (int mi = 0; mi < NIH; ++mi) {
+                for (int mi = 0; mi < 4; ++mi) {
                     if (mh == 1 && mi >= MI1) continue;
                     const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + (lane & 15));
-                    ok[mi] = p < pend;
+                    ok[mh][mi] = p < pend;
                     int n, oy, ox;
-                    split(ok[mi] ? p : cur.p0, n, oy, ox);
-                    yo[mi] = (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (size_t)a.y_ld;
-                    go[mi] = (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld;
-                    // the gate chunks of the whole half first: a load behind a store is issued behind it, and one wave group has
-                    // nothing else to hide a latency under
-                    if (epi & DBX_EPI_GATE) {
-                        const int nc = L.wc * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;
+                    split(ok[mh][mi] ? p : cur.p0, n, oy, ox);
+                    yo[mh][mi] = (unsigned)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (unsigned)a.y_ld;
+                    if constexpr (EPIK == 2) {
+                        const size_t go = (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld;
 #pragma unroll
-                        for (int nh = 0; nh < 2; ++nh) gt[mi][nh] = *(const u32x4*)(gbase + go[mi] + nh * 128 + nc);
+                        for (int nh = 0; nh < 2; ++nh) gt[mh][mi][nh] = *(const u32x4*)(gbase + go + nh * 128 + nc);
                     }
                 }
 #pragma unroll
-                for (int mi = 0; mi < NIH; ++mi) {
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
                     if (mh == 1 && mi >= MI1) continue;
 #pragma unroll
                     for (int nh = 0; nh < 2; ++nh) {
-                        f32x4 v0 = acc.v[mh][nh][mi][0] + bias[nh][0], v1 = acc.v[mh][nh][mi][1] + bias[nh][1];
-                        if (epi & DBX_EPI_RELU) {
+                        f32x4 v0 = acc.v[mh][nh][mi][0], v1 = acc.v[mh][nh][mi][1];
+                        if constexpr (EPIK == 0) { v0 += bias[nh][0]; v1 += bias[nh][1]; }
+                        if (EPIK == 0 && (epi & DBX_EPI_RELU)) {
                             v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
                             v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
                         }
                         u32x4 o = pair_exchange<T>(v0, v1);                  // all lanes: eight consecutive couts at pair_cout_off
-                        if (epi & DBX_EPI_GATE) o = gate_packed16(o, gt[mi][nh]);
-                        if (ok[mi]) *(u32x4*)(ybase + yo[mi] + nh * 128 + L.wc * 32 + pair_cout_off(g4, 0)) = o;
+                        if constexpr (EPIK == 2) o = gate_packed16(o, gt[mh][mi][nh]);
+                        if (ok[mh][mi]) *(u32x4*)(ybase + (size_t)yo[mh][mi] + nh * 128 + nc) = o;
                     }
                 }
-            }
         };
         if (cur.nf == 8) body(pipe::IC<4>{});
         else body(pipe::IC<3>{});
@@ -219,12 +310,23 @@ static inline bool p8_schedule(long long M, int ntile_n, int ncu, P8Args& t) {
     return t.base == 8 ? t.extra == 0 : t.base == 7;                    // the kernel has 7- and 8-unit tiles
 }
 
-template <typename T, int KS>
+template <typename T, int KS, int EPIK = 0, int FLAGS = p8::FL_STAGGER | p8::FL_TSYNC>
 static int launch_conv_p8(const ConvArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
+#ifdef DBX_P8_AB
+        // same-box A/B (tools/build_variant.sh -DDBX_P8_AB): DBX_P8_TSYNC=0 runs the instantiation whose wave groups stay one phase apart across
+        // the tile seams (their epilogues then run one after the other).  Measured: the groups meeting at every seam is 0.8 % of the step faster
+        // (8.987 -> 8.917 ms, three alternating pairs; heads forward 879 -> 851 us, the gated data gradients -3 %)
+        if constexpr (FLAGS == (p8::FL_STAGGER | p8::FL_TSYNC)) {
+            static int tsync = -1;
+            if (tsync < 0) { const char* e = getenv("DBX_P8_TSYNC"); tsync = e ? atoi(e) : 1; }
+            if (!tsync) return launch_conv_p8<T, KS, EPIK, p8::FL_STAGGER>(a, s);
+        }
+#endif
+        constexpr int LDS = p8::LDS_BYTES + (EPIK == 1 ? 32768 : 0);        // + the two groups' 16-KB reduction areas of the fused second convs
         static DbxDevOnce attr_once; int attr_dev = 0;
         if (attr_once.pending(&attr_dev)) {
-            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_p8_kernel<T, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, p8::LDS_BYTES));
+            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_p8_kernel<T, KS, FLAGS, EPIK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
             attr_once.mark(attr_dev);
         }
         static int ncu = 0;
@@ -239,7 +341,7 @@ static int launch_conv_p8(const ConvArgs& a, hipStream_t s) {
         t.HW = a.HoWo; t.W = a.Wo;
         t.inv_HW = 1.0f / (float)a.HoWo; t.inv_W = 1.0f / (float)a.Wo;
         const int grid = t.items < ncu ? t.items : ncu;
-        hipLaunchKernelGGL((conv3x3_p8_kernel<T, KS>), dim3(grid), dim3(512), p8::LDS_BYTES, s, a, t);
+        hipLaunchKernelGGL((conv3x3_p8_kernel<T, KS, FLAGS, EPIK>), dim3(grid), dim3(512), LDS, s, a, t);
         DBX_LAUNCH_CHECK();
     }
     return DBX_OK;

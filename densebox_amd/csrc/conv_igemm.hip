@@ -1565,11 +1565,14 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         const bool k1 = d->kh == 1 && d->kw == 1 && d->cpad == 0;
         const int kk = d->epilogue & ~(DBX_EPI_BIAS | DBX_CONV_WFRAG);
         const int taps = d->kh * d->kw;
-        bool p8_ok = p8_level != 0 && !smallc && sizeof(T) == 2 && (k3 || k1) && !(d->epilogue & DBX_CONV_WFRAG) && !y2 && !pool_idx && !w2_frag &&
-                     (kk == 0 || kk == DBX_EPI_RELU || kk == DBX_EPI_GATE) && d->cin_pad % 64 == 0 && (taps * (d->cin_pad / 64)) % 2 == 0 &&
+        // the heads' forward GEMM: bias + hash dropout (+ the second 1x1 convs on the tile when the caller hands over their weights)
+        const bool heads = k1 && (d->epilogue & ~DBX_CONV_WFRAG) == (DBX_EPI_BIAS | DBX_EPI_DROPHASH);
+        bool p8_ok = p8_level != 0 && !smallc && sizeof(T) == 2 && (k3 || k1) && !(d->epilogue & DBX_CONV_WFRAG) && !y2 && !pool_idx && (heads || !w2_frag) &&
+                     (kk == 0 || kk == DBX_EPI_RELU || (kk == DBX_EPI_GATE && !(d->epilogue & DBX_EPI_BIAS)) || heads) && d->cin_pad % 64 == 0 && (taps * (d->cin_pad / 64)) % 2 == 0 &&
                      taps * (d->cin_pad / 64) >= 4 && taps * (d->cin_pad / 64) < 7000 && d->cout_pad % 256 == 0 && y->c == d->cout_pad &&
                      (y->c_off * ES) % 16 == 0 && (y->ld * ES) % 16 == 0 && a.M < (1 << 24) &&
-                     (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < ((int64_t)1 << 32) && (int64_t)64 * a.ktot_bytes < ((int64_t)1 << 31);
+                     (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < ((int64_t)1 << 32) && (int64_t)64 * a.ktot_bytes < ((int64_t)1 << 31) &&
+                     (int64_t)y->n * a.y_hp * a.y_wp * y->ld < ((int64_t)1 << 32);            // 32-bit byte offsets into x, element offsets into y
         if (p8_ok && (d->epilogue & DBX_EPI_GATE) && gate) p8_ok = (gate->c_off * ES) % 16 == 0 && (gate->ld * ES) % 16 == 0;
         if (p8_ok) {
             static int ncu = 0;
@@ -1577,16 +1580,25 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             P8Args ts;
             p8_ok = p8_schedule(a.M, y->c / 256, ncu, ts) && ts.items >= (ncu * 3) / 4;                 // 7- / 8-unit tiles that fill the chip
         }
-        const bool p8_pref = k3 && d->cin_pad >= 128;
-        if (p8_ok && (p8_pref || p8_level >= 2)) {
+        // preferred: every eligible 3x3 layer with >= 128 input channels (same-box A/B per layer: tools/gpu_conv_plan_bench.py), and the long-K
+        // 1x1 GEMMs (the heads' 2048 -> 512 data gradient at 30 x 30: 150 -> 108 us; tools/gpu_conv1x1_bench.py)
+        // ... and the heads' forward GEMM with its fused epilogue (DBX_P8_HEADS=0: the ws kernel keeps it)
+        static int p8_heads = -1;
+        if (p8_heads < 0) { const char* e = getenv("DBX_P8_HEADS"); p8_heads = e ? atoi(e) : 1; }
+        const bool p8_pref = (k3 && d->cin_pad >= 128) || (k1 && !heads && d->cin_pad >= 1024) || (heads && p8_heads != 0);
+        if (p8_ok && (p8_pref || (p8_level >= 2 && !heads))) {
             a.ntile_n = y->c / 256;
             if (plan) {
                 plan->kernel = DBX_K_P8; plan->tile_m = 256; plan->tile_n = 256; plan->w_frag = 0;
-                snprintf(plan->name, sizeof plan->name, "conv3x3_p8_kernel<%s,%d>", tname, k3 ? 3 : 1);
+                if (heads) snprintf(plan->name, sizeof plan->name, "conv3x3_p8_kernel<%s,1,1>", tname);      // <T, KS, EPIK>
+                else snprintf(plan->name, sizeof plan->name, "conv3x3_p8_kernel<%s,%d>", tname, k3 ? 3 : 1);
                 return DBX_OK;
             }
+            if (heads) return launch_conv_p8<T, 1, 1>(a, s);
+            if (kk == DBX_EPI_GATE) return k3 ? launch_conv_p8<T, 3, 2>(a, s) : launch_conv_p8<T, 1, 2>(a, s);
             return k3 ? launch_conv_p8<T, 3>(a, s) : launch_conv_p8<T, 1>(a, s);
         }
+        DBX_REQUIRE(!(w2_frag && !(d->epilogue & DBX_CONV_WFRAG)), "heads forward fused: plain-layout weights, but the problem does not qualify for the 8-phase kernel (ask dbx_heads_forward_fusable)");
     }
     // Wide 16-bit layers with enough tiles to fill the chip: register-streamed weights (conv3x3_ws.hpp) -- the 3x3 / pad 1
     // backbone layers on congruent frames and the 1x1 head GEMMs (768 -> 512 heads forward; its split-destination data
@@ -1831,21 +1843,33 @@ static bool heads_fused_shape_ok(const dbx_conv_desc* d, const dbx_view* x, cons
     if (d->dtype == DBX_F32 || d->kh != 1 || d->kw != 1 || d->cpad != 0 || d->cout_pad != 512 * nh || hid->c != 512 * nh) return false;
     if ((d->epilogue & ~DBX_CONV_WFRAG) != (DBX_EPI_BIAS | DBX_EPI_DROPHASH)) return false;
     for (int i = 0; i < nh; ++i) if (k[i] < 1 || k[i] > 8) return false;
+    return true;
+}
+// which kernel takes the heads' forward GEMM with the second convs fused: 1 = the 1x1 ws kernel (fragment-order weights, DBX_CONV_WFRAG),
+// 2 = the 8-phase kernel (plain packed weights; second weights as a plain [64][512 nh] image with every head's rows at 0..k-1), 0 = neither
+static int heads_fused_kind(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* hid, const int32_t* k, int nh) {
+    if (!heads_fused_shape_ok(d, x, hid, k, nh)) return 0;
     dbx_conv_plan_t pl;
     dbx_conv_desc dd = *d; dd.epilogue &= ~DBX_CONV_WFRAG;
-    if (dbx_conv_plan(&dd, x, hid, &pl) != DBX_OK) return false;
-    return pl.kernel == DBX_K_WS && strstr(pl.name, ",1,1,1>") != nullptr;       // the 1x1 ws kernel with the fixed epilogue takes this problem
+    if (dbx_conv_plan(&dd, x, hid, &pl) != DBX_OK) return 0;
+    if (pl.kernel == DBX_K_WS && strstr(pl.name, ",1,1,1>") != nullptr) return 1;       // the 1x1 ws kernel with the fixed epilogue takes this problem
+    if (pl.kernel == DBX_K_P8 && strstr(pl.name, ",1,1>") != nullptr) return 2;
+    return 0;
 }
 extern "C" int dbx_heads_forward_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* hid, const int32_t* k, int32_t nh) {
-    return heads_fused_shape_ok(d, x, hid, k, nh) ? 1 : 0;
+    return heads_fused_kind(d, x, hid, k, nh);
 }
 extern "C" int64_t dbx_heads_forward_fused_scratch_bytes(int32_t nh, int64_t pixels) { return (int64_t)2 * nh * pixels * 8 * 4 + 256; }
 static int heads_forward_fused_impl(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,
                                     const void* w2_frag, const float* bias2, const int32_t* k, int32_t nh, float* out_nchw, float* const* outs,
                                     void* scratch, void* stream) {
     if (!d || !x || !hid || !w1_frag || !bias1 || !w2_frag || !bias2 || !k || (!out_nchw && !outs) || !scratch) { dbx_set_error("heads forward fused: null argument"); return DBX_ERR_ARG; }
-    DBX_REQUIRE((d->epilogue & DBX_CONV_WFRAG) && heads_fused_shape_ok(d, x, hid, k, nh),
-                "heads forward fused: needs the 16-bit 1x1 768 -> 512 nh GEMM the ws kernel takes (fragment-order weights, bias + hash dropout), nh <= 4 heads of <= 8 outputs");
+    {
+        // fragment-order weights (DBX_CONV_WFRAG): the ws kernel, wherever it can run the problem; plain weights: the 8-phase kernel, where the plan gives it the problem
+        const int kind = heads_fused_kind(d, x, hid, k, nh);
+        DBX_REQUIRE((d->epilogue & DBX_CONV_WFRAG) ? heads_fused_shape_ok(d, x, hid, k, nh) : kind == 2,
+                    "heads forward fused: needs the 16-bit 1x1 768 -> 512 nh GEMM with bias + hash dropout, nh <= 4 heads of <= 8 outputs, and the weight layout of the kernel dbx_heads_forward_fusable names");
+    }
     float* part = (float*)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     int rc;
     if (d->dtype == DBX_F16) rc = conv_forward_t<_Float16>(d, x, w1_frag, bias1, hid, nullptr, nullptr, 0, (hipStream_t)stream, nullptr, nullptr, 0, 0, nullptr, nullptr, w2_frag, part);

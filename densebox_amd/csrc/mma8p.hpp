@@ -37,6 +37,7 @@ namespace p8 {
 constexpr int LDS_BYTES = 131072;
 constexpr int FL_PRIO = 1;        // s_setprio 1 around the MFMA cluster
 constexpr int FL_STAGGER = 2;     // the two wave groups run one barrier apart
+constexpr int FL_TSYNC = 8;       // persistent kernels: the wave groups meet at every tile seam (their epilogues run side by side) and part again behind it
 constexpr int FL_SAFE = 4;        // debugging: every phase drains vmcnt / lgkmcnt in front of its first barrier (separates layout bugs from ordering bugs)
 
 template <int MF> struct Acc;
@@ -137,11 +138,18 @@ template <int FLAGS, int MF>
 __device__ __forceinline__ void start(const Lanes<MF>& L) {
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     barrier();
-    if ((FLAGS & FL_STAGGER) && L.wr == 1) barrier();
+    if ((FLAGS & FL_STAGGER) && !(FLAGS & FL_TSYNC) && L.wr == 1) barrier();
+}
+// FL_TSYNC: around every tile's ktiles()
+template <int FLAGS, int MF> __device__ __forceinline__ void tile_begin(const Lanes<MF>& L) {
+    if ((FLAGS & FL_STAGGER) && (FLAGS & FL_TSYNC) && L.wr == 1) barrier();
+}
+template <int FLAGS, int MF> __device__ __forceinline__ void tile_end(const Lanes<MF>& L) {
+    if ((FLAGS & FL_STAGGER) && (FLAGS & FL_TSYNC) && L.wr == 0) barrier();
 }
 template <int FLAGS, int MF>
 __device__ __forceinline__ void finish(const Lanes<MF>& L) {
-    if ((FLAGS & FL_STAGGER) && L.wr == 0) barrier();
+    if ((FLAGS & FL_STAGGER) && !(FLAGS & FL_TSYNC) && L.wr == 0) barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // over-run loads of the stream: nothing lands in the LDS behind this point
     __builtin_amdgcn_sched_barrier(0);
 }

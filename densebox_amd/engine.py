@@ -345,6 +345,19 @@ class Engine:
             return out
         return self._packed(('heads2', 4, dt), build, tuple((w._version, w.data_ptr()) for w in ws))
 
+    def _w_heads2_rows0(self, dt):
+        """Stage-2 head weights for the fused heads forward on the 8-phase kernel: one plain (mode 0) image of 64 rows x 512 nh columns, head
+        i's k_i rows at rows 0.. and columns 512 i.. -- a lane's MFMA fragment (row = output, eight consecutive hidden channels) is one
+        16-byte load."""
+        heads = _HEADS[self.kind]
+        ws = [self._param('conv5_2_%s.weight' % s) for s, _ in heads]
+
+        def build(out):
+            for i, w in enumerate(ws):
+                out = self._pack(dt, 0, w, 64, 512 * len(ws), 1, 1, out=out, row_off=0, k_off=512 * i)
+            return out
+        return self._packed(('heads2', 'rows0', dt), build, tuple((w._version, w.data_ptr()) for w in ws))
+
     def _heads_fused(self, P, dt):
         """Both 1x1 convs of the heads in one kernel (dbx_heads_forward_fused)?  16-bit training plans whose 768 -> 512 nh GEMM runs on the
         register-streamed-weights kernel with hash dropout; DBX_HEADS_FUSED=0 keeps the two GEMMs (A/B, tests)."""
@@ -353,11 +366,11 @@ class Engine:
         if r is None:
             heads = _HEADS[self.kind]
             nh = len(heads)
-            r = False
-            if P.train and dt != _lib.F32 and os.environ.get('DBX_HEADS_FUSED', '1') != '0' and self._frag_heads(P, dt, 'f'):
-                d = ConvDesc(dt, 1, 1, 0, 768, 512 * nh, _lib.EPI_BIAS | _lib.EPI_DROPHASH | _lib.CONV_WFRAG, 0)
+            r = 0           # 0: two GEMMs; 1: fused on the ws kernel (fragment-order weights); 2: fused on the 8-phase kernel (plain weights)
+            if P.train and dt != _lib.F32 and os.environ.get('DBX_HEADS_FUSED', '1') != '0':
+                d = ConvDesc(dt, 1, 1, 0, 768, 512 * nh, _lib.EPI_BIAS | _lib.EPI_DROPHASH, 0)
                 ks = (C.c_int32 * nh)(*[k for _, k in heads])
-                r = bool(self.L.dbx_heads_forward_fusable(C.byref(d), C.byref(P.B['fusion'].view()), C.byref(P.B['hid'].view()), ks, nh))
+                r = int(self.L.dbx_heads_forward_fusable(C.byref(d), C.byref(P.B['fusion'].view()), C.byref(P.B['hid'].view()), ks, nh))
             P.frag[key] = r
         return r
 
@@ -398,8 +411,10 @@ class Engine:
             self._w_heads1(dt, frag=self._frag_heads(P, dt, 'f'))
             self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
             self._w_heads2(dt)
-            if self._heads_fused(P, dt):
+            if self._heads_fused(P, dt) == 1:
                 self._w_heads2_frag(dt)
+            elif self._heads_fused(P, dt) == 2:
+                self._w_heads2_rows0(dt)
             self._bias(['conv5_2_' + s_ for s_, _ in heads], 64)
         # the refine branch runs from its fp32 parameters (folded 7x7 conv, dbx_refine_backward) unless DBX_REFINE_LINEAR=0 in training
         rf_convs = kind != 'DenseBox' and train and os.environ.get('DBX_REFINE_LINEAR', '1') == '0'
@@ -784,13 +799,16 @@ class Engine:
             big = None
             b1 = self._bias(['conv5_1_' + s_ for s_, _ in heads], 512 * nh)
             b2 = self._bias(['conv5_2_' + s_ for s_, _ in heads], 64)
-            if hfrag and P.drop_hash and self._heads_fused(P, dt):
+            fk = self._heads_fused(P, dt) if (P.drop_hash and not (epi & _lib.EPI_DROPMASK)) else 0
+            if fk == 1 and not hfrag:
+                fk = 0
+            if fk:
                 # both 1x1 convs of every head in one pass: the second (512 -> k) runs on the hidden tile while it is in registers;
                 # the 944 MB hidden map is written for the backward pass but not read back (dbx_heads_forward_fused)
                 need = L.dbx_heads_forward_fused_scratch_bytes(nh, n * h4 * w4)
                 if getattr(self, '_hf_scratch', None) is None or self._hf_scratch.numel() < need:
                     self._hf_scratch = torch.empty(int(need), dtype=torch.uint8, device=dev)
-                d = ConvDesc(dt, 1, 1, 0, 768, 512 * nh, epi | _lib.CONV_WFRAG, P.drop_seed)
+                d = ConvDesc(dt, 1, 1, 0, 768, 512 * nh, epi | (_lib.CONV_WFRAG if fk == 1 else 0), P.drop_seed)
                 prof = self.profile
                 if prof is not None:
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -798,13 +816,13 @@ class Engine:
                 # every head's own contiguous [N][k][H][W] tensor, as the reference returns them (no slice copies)
                 for stem, k in heads:
                     outs[stem] = torch.empty((n, k, h4, w4), dtype=torch.float32, device=dev)
-                check(L.dbx_heads_forward_fused_heads(C.byref(d), C.byref(B['fusion'].view()), ptr(self._w_heads1(dt, frag=True)), ptr(b1),
-                                                      C.byref(B['hid'].view()), ptr(self._w_heads2_frag(dt)), ptr(b2),
+                check(L.dbx_heads_forward_fused_heads(C.byref(d), C.byref(B['fusion'].view()), ptr(self._w_heads1(dt, frag=fk == 1)), ptr(b1),
+                                                      C.byref(B['hid'].view()), ptr(self._w_heads2_frag(dt) if fk == 1 else self._w_heads2_rows0(dt)), ptr(b2),
                                                       (C.c_int32 * nh)(*[k for _, k in heads]), nh,
                                                       (C.c_void_p * nh)(*[outs[stem].data_ptr() for stem, _ in heads]), ptr(self._hf_scratch), s))
                 if prof is not None:
                     ev1.record()
-                    prof.append({'kernel': 'conv3x3_ws_kernel<%s,1,1,2>' % ('f16', 'bf16', 'f32')[dt],
+                    prof.append({'kernel': ('conv3x3_ws_kernel<%s,1,1,2>' if fk == 1 else 'conv3x3_p8_kernel<%s,1,1>') % ('f16', 'bf16', 'f32')[dt],
                                  'flops': 2.0 * n * h4 * w4 * (768 * 512 * nh + 512 * ktot), 'start': ev0, 'end': ev1})
             else:
                 self._conv(dt, B['fusion'].view(), B['hid'].view(), self._w_heads1(dt, frag=hfrag), b1, 1, 1, 0, 768, 512 * nh,

@@ -42,8 +42,10 @@ const char* dbx_last_error(void);
  *      the dbx_pack_multi job record's former pad field became rows_lim
  *   3  (round 4) fused entry points added (see the round-4 section below); nothing removed
  *   4  (round 4) dbx_head2_backward_up takes a d_hid view with a NULL ptr ("do not store it"); heads-gen entry points added
- *   5  (round 4) dbx_sgd_pack_step and dbx_heads_forward_fused_heads added; nothing changed */
-#define DBX_ABI_VERSION 5
+ *   5  (round 4) dbx_sgd_pack_step and dbx_heads_forward_fused_heads added; nothing changed
+ *   6  (round 5) dbx_conv_plan may name DBX_K_P8 (the 8-phase kernel: plain packed weights); dbx_heads_forward_fusable returns WHICH kernel
+ *      takes the fused heads forward (1 = ws / fragment-order weights as before, 2 = 8-phase / plain weights + plain second-weight image) */
+#define DBX_ABI_VERSION 6
 int dbx_version(void);
 /* device sanity: returns gfx arch number (950) of `device`, or <0 */
 int dbx_device_arch(int device);
@@ -111,8 +113,12 @@ int dbx_conv_plan(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y, 
  * from the tile while it is in registers (the rounded, dropped values that land in `hid`; fp32 accumulation; fixed summation order).
  * w2_frag: the nh second weights as ONE dbx_pack_weight mode-4 image of 256 rows x (512 nh) columns, head i's k_i rows at rows
  * 0..k_i-1 (row_off 0) and columns 512 i.. (k_off 512 i).  scratch: dbx_heads_forward_fused_scratch_bytes(nh, N H W).
- * dbx_heads_forward_fusable() = 1 where the call is available (16-bit types, k_i <= 8, the problems dbx_conv_plan gives to the 1x1
- * register-streamed-weights kernel); elsewhere run dbx_conv_forward twice. */
+ * dbx_heads_forward_fusable() names the kernel that takes the call (16-bit types, k_i <= 8), 0 = none (run dbx_conv_forward twice):
+ *   1 = the 1x1 register-streamed-weights kernel: d->epilogue carries DBX_CONV_WFRAG, w1_frag / w2_frag are the mode-4 images above;
+ *   2 = the 8-phase kernel (round 5; ABI version 6): NO DBX_CONV_WFRAG, w1_frag = the plain dbx_pack_weight mode-0 image [512 nh][768],
+ *       w2_frag = ONE plain mode-0 image of 64 rows x (512 nh) columns, head i's k_i rows at rows 0..k_i-1 (row_off 0) and columns 512 i..
+ *       (k_off 512 i), zero elsewhere.  Same scratch, same outputs, same dropout masks (dbx_drop_hash32 of seed, pixel, channel / 32).
+ * A caller that passes DBX_CONV_WFRAG always gets the ws kernel where that one can run the problem. */
 int dbx_heads_forward_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* hid, const int32_t* k, int32_t nh);
 int64_t dbx_heads_forward_fused_scratch_bytes(int32_t nh, int64_t pixels);
 int dbx_heads_forward_fused(const dbx_conv_desc* d, const dbx_view* x, const void* w1_frag, const float* bias1, const dbx_view* hid,

@@ -396,7 +396,10 @@ def test_conv_ws_1x1_forward_bias_and_hash_dropout(dtn):
             d = ConvDesc(dt, 1, 1, 0, ci, co, epi, 0x1234)
             plan = _lib.ConvPlan()
             check(L.dbx_conv_plan(C.byref(d), C.byref(xv), C.byref(yv), C.byref(plan)))
-            assert plan.kernel == _lib.K_WS and plan.name.decode().startswith('conv3x3_ws_kernel<') and ',1,1,' in plan.name.decode()
+            if plan.kernel == _lib.K_P8:     # round 5: the plan gives the bias + hash-dropout GEMM to the 8-phase kernel (plain weights: the frag = False arm)
+                assert epi & _lib.EPI_DROPHASH and plan.name.decode().endswith(',1,1>') and not plan.w_frag
+            else:
+                assert plan.kernel == _lib.K_WS and plan.name.decode().startswith('conv3x3_ws_kernel<') and ',1,1,' in plan.name.decode()
             if frag:
                 d = ConvDesc(dt, 1, 1, 0, ci, co, epi | _lib.CONV_WFRAG, 0x1234)
             check(L.dbx_conv_forward(C.byref(d), C.byref(xv), ptr(pack(L, dt, wt, ci, co, mode=4 if frag else 0)), ptr(b), C.byref(yv),
@@ -404,7 +407,8 @@ def test_conv_ws_1x1_forward_bias_and_hash_dropout(dtn):
             outs[(frag, epi)] = ty.permute(0, 3, 1, 2).float()
     plain = outs[(True, _lib.EPI_BIAS)]
     assert torch.allclose(plain, ref, rtol=tol, atol=tol), (plain - ref).abs().max().item()
-    # hash dropout: the same keep bits as the LDS-ring kernel (same seed, pixel and channel counters), kept values doubled
+    # hash dropout: the same keep bits as the kernel that takes plain weights (the 8-phase kernel, or the LDS-ring kernel under DBX_P8=0): same
+    # seed, pixel and channel counters, kept values doubled
     a, bb = outs[(True, _lib.EPI_BIAS | _lib.EPI_DROPHASH)], outs[(False, _lib.EPI_BIAS | _lib.EPI_DROPHASH)]
     assert torch.allclose(a, bb, rtol=tol, atol=tol)
     big = ref.abs() > 0.1
@@ -992,6 +996,74 @@ def test_heads_forward_fused_equals_the_two_gemms(ks, n, h, w, dtn):
     # about half of the hidden map is dropped, the rest doubled: the dropout bits are live
     frac = float((ta == 0).float().mean())
     assert 0.35 < frac < 0.85, frac
+
+
+@pytest.mark.parametrize('dtn', ['f16', 'bf16'])
+@pytest.mark.parametrize('ks,n,h,w', [([1, 4, 4, 8], 3, 60, 60), ([1, 4], 6, 60, 60), ([1, 4, 4, 8], 2, 57, 83)])
+def test_heads_forward_fused_on_the_8phase_kernel(ks, n, h, w, dtn):
+    """The same call on the 8-phase kernel (dbx_heads_forward_fusable == 2: plain packed weights, the second weights as a plain [64][512 nh]
+    image with every head's rows at 0..): the hidden map against fp32 torch on the rounded operands with the SAME keep bits as the ws
+    kernel's (the backward kernels regenerate them from the hash), the head outputs against the second conv of the hidden map it wrote
+    (fp32 summation order), the per-head destinations bitwise the [N][sum k][H][W] form, and a second launch bitwise equal."""
+    if os.environ.get('DBX_P8') == '0' or os.environ.get('DBX_P8_HEADS') == '0' or os.environ.get('DBX_CONV_VARIANT'):
+        pytest.skip('this process keeps the heads forward off the 8-phase kernel')
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    nh, ktot = len(ks), sum(ks)
+    g = torch.Generator(device='cpu').manual_seed(78)
+    x = torch.relu(torch.randn(n, 768, h, w, generator=g)).cuda()
+    w1 = (torch.randn(512 * nh, 768, 1, 1, generator=g) * 0.05).cuda()
+    b1 = torch.randn(512 * nh, generator=g).cuda()
+    w2 = [(torch.randn(k, 512, 1, 1, generator=g) * 0.05).cuda().contiguous() for k in ks]
+    b2 = torch.zeros(64, device='cuda'); b2[:ktot] = torch.randn(ktot, generator=g).cuda()
+    fx, tx, xv = framed(x, 1, tdt)
+    seed = 0x1234ABCD
+    d = ConvDesc(dt, 1, 1, 0, 768, 512 * nh, _lib.EPI_BIAS | _lib.EPI_DROPHASH, seed)
+    karr = (C.c_int32 * nh)(*ks)
+    fa, ta, hva = framed(torch.zeros(n, 512 * nh, h, w), 0, tdt)
+    assert L.dbx_heads_forward_fusable(C.byref(d), C.byref(xv), C.byref(hva), karr, nh) == 2
+    w1p = pack(L, dt, w1, 768, 512 * nh, mode=0)
+    d2 = ConvDesc(dt, 1, 1, 0, 512 * nh, 64, 0)
+    w2p = torch.zeros(L.dbx_conv_packed_elems(C.byref(d2)) * 2, dtype=torch.uint8, device='cuda')
+    for i, (wt, k) in enumerate(zip(w2, ks)):
+        check(L.dbx_pack_weight(dt, 0, ptr(wt), k, 512, 1, 1, ptr(w2p), 64, 512 * nh, 0, 512 * i, stream_ptr()))
+    sc = torch.empty(L.dbx_heads_forward_fused_scratch_bytes(nh, n * h * w), dtype=torch.uint8, device='cuda')
+    res = []
+    for rep in range(2):
+        fa, ta, hva = framed(torch.zeros(n, 512 * nh, h, w), 0, tdt)
+        out_a = torch.full((n, ktot, h, w), 7.0, device='cuda')
+        check(L.dbx_heads_forward_fused(C.byref(d), C.byref(xv), ptr(w1p), ptr(b1), C.byref(hva), ptr(w2p), ptr(b2), karr, nh, ptr(out_a), ptr(sc),
+                                        stream_ptr()))
+        torch.cuda.synchronize()
+        res.append((fa, ta, out_a))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    fa, ta, out_a = res[0]
+    outs_h = [torch.full((n, k, h, w), 7.0, device='cuda') for k in ks]
+    fc, tc, hvc = framed(torch.zeros(n, 512 * nh, h, w), 0, tdt)
+    check(L.dbx_heads_forward_fused_heads(C.byref(d), C.byref(xv), ptr(w1p), ptr(b1), C.byref(hvc), ptr(w2p), ptr(b2), karr, nh,
+                                          (C.c_void_p * nh)(*[o.data_ptr() for o in outs_h]), ptr(sc), stream_ptr()))
+    # the ws kernel on the same problem (fragment-order weights): the same keep bits, values equal up to the output rounding
+    dw = ConvDesc(dt, 1, 1, 0, 768, 512 * nh, _lib.EPI_BIAS | _lib.EPI_DROPHASH | _lib.CONV_WFRAG, seed)
+    fb, tb, hvb = framed(torch.zeros(n, 512 * nh, h, w), 0, tdt)
+    check(L.dbx_conv_forward(C.byref(dw), C.byref(xv), ptr(pack(L, dt, w1, 768, 512 * nh, mode=4)), ptr(b1), C.byref(hvb), None, None, 0, stream_ptr()))
+    # ... and the 8-phase kernel without the second convs (plain dbx_conv_forward on the same descriptor): bitwise the fused call's hidden map
+    fd, td, hvd = framed(torch.zeros(n, 512 * nh, h, w), 0, tdt)
+    check(L.dbx_conv_forward(C.byref(d), C.byref(xv), ptr(w1p), ptr(b1), C.byref(hvd), None, None, 0, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(fa, fc) and torch.equal(torch.cat(outs_h, 1), out_a) and torch.equal(fa, fd)
+    hid, hid_ws = ta.permute(0, 3, 1, 2).float(), tb.permute(0, 3, 1, 2).float()
+    ref = F.conv2d(x.to(tdt).float(), w1.to(tdt).float(), b1)
+    tol = (2e-2 if dtn == 'bf16' else 3e-3)
+    big = ref.abs() > 0.1
+    assert torch.equal((hid != 0)[big], (hid_ws != 0)[big])
+    assert torch.allclose(hid, hid_ws, rtol=tol, atol=tol)
+    kept = big & (hid != 0)
+    assert torch.allclose(hid[kept], 2 * ref[kept], rtol=2 * tol, atol=2 * tol)
+    frac = float((hid == 0).float().mean())
+    assert 0.35 < frac < 0.85, frac
+    out_ref = torch.cat([F.conv2d(hid[:, 512 * i:512 * (i + 1)], w2[i].to(tdt).float()) for i in range(nh)], 1) + b2[:ktot].view(1, -1, 1, 1)
+    scale = float(out_ref.abs().max())
+    assert float((out_a - out_ref).abs().max()) <= 1e-4 * scale, (float((out_a - out_ref).abs().max()), scale)
 
 
 @pytest.mark.parametrize('dtn', ['f16', 'bf16'])
