@@ -346,3 +346,215 @@ static int launch_conv_p8(const ConvArgs& a, hipStream_t s) {
     }
     return DBX_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ 128-cout layers: 512-pixel x 128-cout tiles
+// The same kernel on the p8w core (mma8p.hpp): a tile is 16, 15 or 14 units of 32 pixels (m halves 2 and 3 of a wave with four or three
+// fragments), one cout tile of 128; everything else (compact pixels, K order, continuous stream, seam-synchronised epilogues) as above.
+// conv2_2 (128 -> 128 at 120 x 120) forward and data gradient, conv3_1's data gradient (256 -> 128 at 60 x 60).
+template <typename T, int KS, int EPIK = 0>
+__global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, const P8Args t) {
+    constexpr int ES = sizeof(T);
+    static_assert(ES == 2 && (EPIK == 0 || EPIK == 2), "16-bit types; bias / ReLU or gate epilogue");
+    constexpr int NTAPS = KS * KS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const p8w::Lanes L = p8w::lanes(smem);
+    const int lane = L.lane, wave = L.wave;
+    const int pix_bytes = a.x_ld * ES;
+    const int nkt = t.nkt;
+    const int cin_bytes = a.cpt * 16;
+    const int G = gridDim.x;
+    int item = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;       // an XCD works on neighbouring pixel tiles
+    if (item >= t.items) return;
+
+    struct Tile { int p0, nf, n0; };
+    auto tile_of = [&](int it) {
+        Tile r;
+        const int tm = it / a.ntile_n, tn = it - tm * a.ntile_n;
+        const int u0 = tm * t.base + (tm < t.extra ? tm : t.extra);
+        r.nf = t.base + (tm < t.extra ? 1 : 0);
+        r.p0 = u0 * 32;
+        r.n0 = tn * 128;
+        return r;
+    };
+    auto split = [&](int p, int& n, int& oy, int& ox) {
+        n = (int)(((float)p + 0.5f) * t.inv_HW);
+        int r = p - n * t.HW;
+        if (r < 0) { --n; r += t.HW; }
+        if (r >= t.HW) { ++n; r -= t.HW; }
+        oy = (int)(((float)r + 0.5f) * t.inv_W);
+        ox = r - oy * t.W;
+        if (ox < 0) { --oy; ox += t.W; }
+        if (ox >= t.W) { ++oy; ox -= t.W; }
+    };
+    // tile row (half mh, LDS row r of its 128) -> pixel offset from p0: a half with three fragments per wave uses rows 0..47 of each wave's 64
+    auto row_index = [&](int nf, int mh, int r) {
+        const int h2 = nf >= 15 ? 128 : 96, h3 = nf == 16 ? 128 : 96;              // pixel rows of halves 2 and 3
+        if (mh < 2) return mh * 128 + r;
+        const int rows = mh == 2 ? h2 : h3, off = mh == 2 ? 256 : 256 + h2;
+        const int w = r & 63;
+        return off + (r >> 6) * (rows >> 1) + (w < (rows >> 1) ? w : 0);
+    };
+    const unsigned chunk16 = p8::src_chunk(wave, lane) << 4;
+    auto a_offsets = [&](const Tile& tl, unsigned (&vo)[4][2]) {
+#pragma unroll
+        for (int mh = 0; mh < 4; ++mh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int p = tl.p0 + row_index(tl.nf, mh, j * 64 + wave * 8 + (lane >> 3));
+                p = p < a.M ? p : a.M - 1;
+                int n, oy, ox;
+                split(p, n, oy, ox);
+                vo[mh][j] = (unsigned)((n * a.x_hp + oy + a.x_org) * a.x_wp + ox + a.x_org) * (unsigned)pix_bytes + chunk16;
+            }
+    };
+    const unsigned voB = (unsigned)((wave * 8 + (lane >> 3)) * a.ktot_bytes) + chunk16;
+    Tile cur = tile_of(item), nxt = cur;
+    unsigned vcur[4][2], vnxt[4][2];
+    a_offsets(cur, vcur);
+#pragma unroll
+    for (int mh = 0; mh < 4; ++mh)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vnxt[mh][j] = vcur[mh][j];
+    auto k_split = [&](int kt, bool& nx, int& chunk, int& tap) {
+        nx = kt >= nkt;
+        const int k = nx ? kt - nkt : kt;
+        if constexpr (NTAPS == 9) { chunk = (k * 7282) >> 16; tap = k - chunk * 9; }
+        else { chunk = k; tap = 0; }
+    };
+    auto stA = [&](int kt, int mh, unsigned dst) {
+        bool nx; int chunk, tap;
+        k_split(kt, nx, chunk, tap);
+        int toff = 0;
+        if constexpr (NTAPS == 9) { const int ky = (tap * 11) >> 5, kx = tap - 3 * ky; toff = (ky * a.x_wp + kx) * pix_bytes; }
+        const char* b = a.x + toff + chunk * 128;
+        p8::glds(b, nx ? vnxt[mh][0] : vcur[mh][0], dst);
+        p8::glds(b, nx ? vnxt[mh][1] : vcur[mh][1], dst + 8192);
+    };
+    auto stB = [&](int kt, unsigned dst) {
+        bool nx; int chunk, tap;
+        k_split(kt, nx, chunk, tap);
+        const char* b = a.w + (size_t)(nx ? nxt.n0 : cur.n0) * a.ktot_bytes + tap * cin_bytes + chunk * 128;
+        p8::glds(b, voB, dst);
+        p8::glds(b + (size_t)64 * a.ktot_bytes, voB, dst + 8192);
+    };
+    const int epi = a.epi;
+    const int g4 = lane >> 4;
+    f32x4 bias[2];
+    int bias_n0 = -1;
+
+    p8w::prologue(L, stA, stB);
+    p8w::start();
+    p8w::Acc acc;
+    for (;;) {
+        const int nxt_item = item + G;
+        const bool more = nxt_item < t.items;
+        if (more) { nxt = tile_of(nxt_item); a_offsets(nxt, vnxt); }
+        p8w::zero(acc);
+        if (EPIK != 2 && cur.n0 != bias_n0) {
+            bias_n0 = cur.n0;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                bias[ni] = (epi & DBX_EPI_BIAS) ? *(const f32x4*)(a.bias + cur.n0 + L.wc * 32 + ni * 16 + 4 * g4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        auto body = [&](auto MI2_, auto MI3_) {
+            constexpr int MI2 = decltype(MI2_)::value, MI3 = decltype(MI3_)::value;
+            p8w::tile_begin(L);
+            p8w::ktiles<T, MI2, MI3>(acc, L, nkt, stA, stB);
+            p8w::tile_end(L);
+            const int pend = cur.p0 + cur.nf * 32 < a.M ? cur.p0 + cur.nf * 32 : a.M;
+            T* const ybase = (T*)a.y + cur.n0;
+            const T* const gbase = (const T*)a.gate + cur.n0;
+            const int nc = L.wc * 32 + pair_cout_off(g4, 0);
+            // two batches of eight pixel rows: addresses + the batch's gate chunks first, then its stores
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                unsigned yo[2][4];
+                bool ok[2][4];
+                u32x4 gt[2][4];
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const int mh = 2 * hb + m2;
+                        if ((mh == 2 && mi >= MI2) || (mh == 3 && mi >= MI3)) continue;
+                        const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + (lane & 15));
+                        ok[m2][mi] = p < pend;
+                        int n, oy, ox;
+                        split(ok[m2][mi] ? p : cur.p0, n, oy, ox);
+                        yo[m2][mi] = (unsigned)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (unsigned)a.y_ld;
+                        if constexpr (EPIK == 2) {
+                            const size_t go = (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld;
+                            gt[m2][mi] = *(const u32x4*)(gbase + go + nc);
+                        }
+                    }
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const int mh = 2 * hb + m2;
+                        if ((mh == 2 && mi >= MI2) || (mh == 3 && mi >= MI3)) continue;
+                        f32x4 v0 = acc.v[mh][mi][0], v1 = acc.v[mh][mi][1];
+                        if constexpr (EPIK == 0) { v0 += bias[0]; v1 += bias[1]; }
+                        if (EPIK == 0 && (epi & DBX_EPI_RELU)) {
+                            v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                            v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+                        }
+                        u32x4 o = pair_exchange<T>(v0, v1);
+                        if constexpr (EPIK == 2) o = gate_packed16(o, gt[m2][mi]);
+                        if (ok[m2][mi]) *(u32x4*)(ybase + (size_t)yo[m2][mi] + nc) = o;
+                    }
+            }
+        };
+        if (cur.nf == 16) body(pipe::IC<4>{}, pipe::IC<4>{});
+        else if (cur.nf == 15) body(pipe::IC<4>{}, pipe::IC<3>{});
+        else body(pipe::IC<3>{}, pipe::IC<3>{});
+        if (!more) break;
+        item = nxt_item;
+        cur = nxt;
+#pragma unroll
+        for (int mh = 0; mh < 4; ++mh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) vcur[mh][j] = vnxt[mh][j];
+    }
+    p8w::finish();
+}
+
+// tiles of 14 .. 16 units of 32 pixels, their number rounded up to whole rounds of CUs
+static inline bool p8w_schedule(long long M, int ntile_n, int ncu, P8Args& t) {
+    const long long units = (M + 31) / 32;
+    long long mt = (units + 15) / 16;
+    const long long wgs = mt * ntile_n;
+    if (wgs > ncu) {
+        const long long up = (wgs + ncu - 1) / ncu * ncu / ntile_n;
+        if (up > mt && units / up >= 14) mt = up;
+    }
+    t.mt = (int)mt; t.base = (int)(units / mt); t.extra = (int)(units % mt);
+    t.items = (int)(mt * ntile_n);
+    return t.base == 16 ? t.extra == 0 : (t.base == 14 || t.base == 15);
+}
+
+template <typename T, int KS, int EPIK = 0>
+static int launch_conv_p8w(const ConvArgs& a, hipStream_t s) {
+    if constexpr (sizeof(T) == 2) {
+        static DbxDevOnce attr_once; int attr_dev = 0;
+        if (attr_once.pending(&attr_dev)) {
+            DBX_HIP(hipFuncSetAttribute((const void*)conv3x3_p8w_kernel<T, KS, EPIK>, hipFuncAttributeMaxDynamicSharedMemorySize, p8w::LDS_BYTES));
+            attr_once.mark(attr_dev);
+        }
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            DBX_HIP(hipGetDevice(&dev));
+            DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        }
+        P8Args t;
+        DBX_REQUIRE(p8w_schedule(a.M, a.ntile_n, ncu, t), "conv p8w: no 14..16-unit tile schedule for %d pixels", a.M);
+        t.nkt = KS * KS * (a.cpt / 8);
+        t.HW = a.HoWo; t.W = a.Wo;
+        t.inv_HW = 1.0f / (float)a.HoWo; t.inv_W = 1.0f / (float)a.Wo;
+        const int grid = t.items < ncu ? t.items : ncu;
+        hipLaunchKernelGGL((conv3x3_p8w_kernel<T, KS, EPIK>), dim3(grid), dim3(512), p8w::LDS_BYTES, s, a, t);
+        DBX_LAUNCH_CHECK();
+    }
+    return DBX_OK;
+}

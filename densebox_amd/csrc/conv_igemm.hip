@@ -1598,6 +1598,31 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
             if (kk == DBX_EPI_GATE) return k3 ? launch_conv_p8<T, 3, 2>(a, s) : launch_conv_p8<T, 1, 2>(a, s);
             return k3 ? launch_conv_p8<T, 3>(a, s) : launch_conv_p8<T, 1>(a, s);
         }
+        // 128-cout layers (conv2_2 forward / data gradient, conv3_1's data gradient): 512-pixel x 128-cout tiles on the p8w core (DBX_P8W=0: off)
+        static int p8w_on = -1;
+        if (p8w_on < 0) { const char* e = getenv("DBX_P8W"); p8w_on = e ? atoi(e) : 1; }
+        bool p8w_ok = p8_level != 0 && p8w_on != 0 && !smallc && sizeof(T) == 2 && k3 && !(d->epilogue & DBX_CONV_WFRAG) && !y2 && !pool_idx && !w2_frag &&
+                      (kk == 0 || kk == DBX_EPI_RELU || (kk == DBX_EPI_GATE && !(d->epilogue & DBX_EPI_BIAS))) && d->cin_pad % 128 == 0 &&
+                      9 * (d->cin_pad / 64) < 7000 && d->cout_pad % 128 == 0 && d->cout_pad % 256 != 0 && y->c == d->cout_pad &&
+                      (y->c_off * ES) % 16 == 0 && (y->ld * ES) % 16 == 0 && a.M < (1 << 24) &&
+                      (int64_t)x->n * a.x_hp * a.x_wp * x->ld * ES < ((int64_t)1 << 32) && (int64_t)64 * a.ktot_bytes < ((int64_t)1 << 31) &&
+                      (int64_t)y->n * a.y_hp * a.y_wp * y->ld < ((int64_t)1 << 32);
+        if (p8w_ok && (d->epilogue & DBX_EPI_GATE) && gate) p8w_ok = (gate->c_off * ES) % 16 == 0 && (gate->ld * ES) % 16 == 0;
+        if (p8w_ok) {
+            static int ncu = 0;
+            if (!ncu) { int dev = 0; DBX_HIP(hipGetDevice(&dev)); DBX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev)); }
+            P8Args ts;
+            p8w_ok = p8w_schedule(a.M, y->c / 128, ncu, ts) && ts.items >= (ncu * 3) / 4;
+        }
+        if (p8w_ok) {
+            a.ntile_n = y->c / 128;
+            if (plan) {
+                plan->kernel = DBX_K_P8; plan->tile_m = 512; plan->tile_n = 128; plan->w_frag = 0;
+                snprintf(plan->name, sizeof plan->name, "conv3x3_p8w_kernel<%s,3>", tname);
+                return DBX_OK;
+            }
+            return kk == DBX_EPI_GATE ? launch_conv_p8w<T, 3, 2>(a, s) : launch_conv_p8w<T, 3>(a, s);
+        }
         DBX_REQUIRE(!(w2_frag && !(d->epilogue & DBX_CONV_WFRAG)), "heads forward fused: plain-layout weights, but the problem does not qualify for the 8-phase kernel (ask dbx_heads_forward_fusable)");
     }
     // Wide 16-bit layers with enough tiles to fill the chip: register-streamed weights (conv3x3_ws.hpp) -- the 3x3 / pad 1

@@ -757,6 +757,255 @@ __global__ __launch_bounds__(512) void wgrad_all9_kernel(const WgradArgs a) {
         a.bpartial[((long long)split * a.tiles_ci + tile_ci) * a.co_pad + tile_co * 128 + wm * 64 + wn * 16 + lane] = bacc.x;
 }
 
+// ------------------------------------------------------------------------------------------------ 3x3 wide layers, round 5: wgrad_all9_kernel's tile with the wave groups one barrier apart
+template <typename T>
+__global__ __launch_bounds__(512) void wgrad_all9s_kernel(const WgradArgs a) {
+    static_assert(sizeof(T) == 2, "16-bit tiles");
+    constexpr int R = 64, BROWS = 72;
+    constexpr int A_BYTES = R * 256, BAND_BYTES = BROWS * 128;
+    constexpr int STAGE = A_BYTES + 3 * BAND_BYTES;                     // 44032 B
+    constexpr int AP = A_BYTES / 1024, BP = 3 * BAND_BYTES / 1024, NPIECE = AP + BP, SLOTS = (NPIECE + 7) / 8;   // 16 + 27 pieces, 6 slots
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // 3 x STAGE = 129 KB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                           // wave tile 64(co) x 16(ci)
+    int t, split;
+    wg_tile_split(a.tiles_co * a.tiles_ci, a.nsplit, t, split);
+    const int tile_ci = t % a.tiles_ci, tile_co = t / a.tiles_ci;
+    // K range: as wgrad_row3_kernel (compact walk over the valid rows of each image when a.spi > 0)
+    const bool compact = a.spi > 0;
+    const int gs0 = compact ? split * a.steps_per_split : (int)(((long long)split * a.rows_per_split) / R);
+    const long long q0 = compact ? 0 : (long long)split * a.rows_per_split;
+    long long q1 = q0 + a.rows_per_split; if (q1 > a.Q) q1 = a.Q;
+    int nsteps = q1 > q0 ? (int)((q1 - q0 + R - 1) / R) : 0;
+    if (compact) { const int gs1 = min(gs0 + a.steps_per_split, a.steps_total); nsteps = gs1 > gs0 ? gs1 - gs0 : 0; }
+
+    // ---- LDS-DMA sources.  A piece = 4 dz rows (lane: row l>>4, chunk position l&15), a B piece = 8 band rows (row l>>3, chunk
+    // position l&7); position p of LDS row r receives source chunk p ^ mask(r) (swz16<128> / swz16<64>): the row bits that come
+    // from the lane are folded into the lane offset, the one that comes from the piece index is a uniform XOR.
+    const long long dzrow = (long long)a.dz_ld * 2, xrow = (long long)a.x_ld * 2;
+    const unsigned laA = (unsigned)(lane >> 4) * (unsigned)dzrow + (unsigned)(((lane & 15) ^ ((lane >> 4) << 1)) << 4);
+    const unsigned laB = (unsigned)(lane >> 3) * (unsigned)xrow + (unsigned)(((lane & 7) ^ (((lane >> 4) & 1) << 1)) << 4);
+    // The tiles are issued in order, so the frame row of the next one is carried as two uniform pointers (dz, x) that advance by
+    // 64 rows, or -- compact walk, last step of an image -- by the jump to the next image's first valid row: no division and no
+    // 64-bit multiply per step.  A slot's piece is fixed for the kernel (piece = wave + 8 slot): its uniform byte offset from
+    // those pointers is computed once.
+    int ij = 0;
+    long long iq0;
+    if (compact) { const int img = gs0 / a.spi; ij = gs0 - img * a.spi; iq0 = (long long)img * a.img_rows + a.row0 + 64LL * ij; }
+    else iq0 = q0;
+    const char* ap = a.dz + tile_co * 256 + iq0 * dzrow;
+    const char* bp = a.x + tile_ci * 128 + ((long long)a.shift0 * (a.wp + 1) + iq0) * xrow;
+    const long long jump = compact ? a.img_rows - 64LL * (a.spi - 1) : 64;
+    const long long a64 = 64 * dzrow, b64 = 64 * xrow, ajmp = jump * dzrow, bjmp = jump * xrow;
+    // piece of slot i = wave + 8 i: slots 0, 1 are dz pieces, 2 .. 5 band pieces (slot 5 of waves 3 .. 7 repeats their slot 4:
+    // every wave issues SLOTS loads, the waits are counted).  The swizzle bit that comes from the piece index depends on the wave
+    // only -> folded into the lane offsets; the row offsets of the slots are six uniform constants.
+    static_assert(AP == 16 && NPIECE == 43 && SLOTS == 6, "slot layout");
+    const unsigned vA = laA ^ (unsigned)(((wave >> 1) & 1) << 7), vB = laB ^ (unsigned)((wave & 1) << 6);
+    const int pb5 = wave < 3 ? wave + 24 : wave + 16;
+    auto boff = [&](int pb) { const int band = pb / 9, pr = pb - band * 9; return (unsigned)(band * a.wp + 8 * pr) * (unsigned)xrow; };
+    const unsigned sA0 = (unsigned)(4 * wave) * (unsigned)dzrow, sA1 = sA0 + 32u * (unsigned)dzrow;
+    const unsigned sB2 = boff(wave), sB3 = boff(wave + 8), sB4 = boff(wave + 16), sB5 = boff(pb5);
+    // The DMA goes out as inline asm (saddr form: uniform base + one lane offset register): for the builtin the compiler's
+    // waitcnt pass puts s_waitcnt vmcnt(0) in front of the next transpose read (it cannot prove that the ds_read_tr intrinsic
+    // does not alias the LDS-DMA destination), which drains the ring every step.  Invisible to that pass, the loads are counted by
+    // hand: the only other VMEM operations of the kernel are the slab stores behind the final vmcnt(0).
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned ldsw = lds0 + wave * 1024, lds5 = lds0 + (AP + pb5) * 1024;
+    int issued = 0;
+    auto glds = [](const char* src, unsigned voff, unsigned dst) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(src), "s"(dst) : "memory");
+    };
+    // A tile's six LDS-DMA go out in three parts of two (one part per phase: an LDS-DMA costs 100+ issue cycles next to a dozen reads); the
+    // pointers advance behind the last part (the last tile again past the end: keeps the counted waits uniform)
+#define ALL9S_PART0(sb) do { glds(ap + sA0, vA, ldsw + (sb)); glds(ap + sA1, vA, ldsw + (sb) + 8 * 1024); } while (0)
+#define ALL9S_PART1(sb) do { glds(bp + sB2, vB, ldsw + (sb) + 16 * 1024); glds(bp + sB3, vB, ldsw + (sb) + 24 * 1024); } while (0)
+#define ALL9S_PART2(sb)                                                                     \
+    do {                                                                                    \
+        glds(bp + sB4, vB, ldsw + (sb) + 32 * 1024); glds(bp + sB5, vB, lds5 + (sb));      \
+        if (++issued < nsteps) {                                                            \
+            if (compact && ++ij == a.spi) { ij = 0; ap += ajmp; bp += bjmp; }               \
+            else { ap += a64; bp += b64; }                                                  \
+        }                                                                                   \
+    } while (0)
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) acc[tp][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 bacc = {0.f, 0.f, 0.f, 0.f};
+    const unsigned one2 = DType<T>::id == DBX_F16 ? 0x3C003C00u : 0x3F803F80u;
+    const u32x4 ones = {one2, one2, one2, one2};
+    const bool do_bias = a.bpartial != nullptr;
+
+    const int g = lane >> 4, rsub = (lane & 15) >> 2, csub = (lane & 3) * 8;
+    auto trd = [&](const char* p) {
+        return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p));
+    };
+    auto rdA = [&](const char* Sb, int kk, int mi) {
+        const int r0 = 32 * kk + 8 * g + rsub, cbyte = (wm * 64 + mi * 16) * 2 + csub;
+        const u32x2 lo = trd(Sb + swz16<128>(r0, cbyte)), hi = trd(Sb + swz16<128>(r0 + 4, cbyte));
+        return (u32x4){lo.x, lo.y, hi.x, hi.y};
+    };
+    struct Run { u32x2 r0, r1, r2; };          // band rows r .. r+11 of one channel column (see wgrad_row3_kernel)
+    auto rdRun = [&](const char* Sb, int kk, int ky) {
+        const int r0 = ky * BROWS + 32 * kk + 8 * g + rsub, cbyte = (wn * 16) * 2 + csub;
+        const char* Bb = Sb + A_BYTES;
+        Run r;
+        r.r0 = trd(Bb + swz16<64>(r0, cbyte)); r.r1 = trd(Bb + swz16<64>(r0 + 4, cbyte)); r.r2 = trd(Bb + swz16<64>(r0 + 8, cbyte));
+        return r;
+    };
+    auto mma = [&](const u32x4& xf, const u32x4& zf, f32x4& c) {
+        if constexpr (DType<T>::id == DBX_F16)
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf), __builtin_bit_cast(f16x8, zf), c, 0, 0, 0);
+        else
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, xf), __builtin_bit_cast(bf16x8, zf), c, 0, 0, 0);
+    };
+
+    // ---- the 8-phase idea on this tile (round 5): the 8 waves are two groups of four (wm = 0 / 1: one wave of each per SIMD) that run the
+    // same phase program ONE BARRIER APART, so that one group's pure cluster of 24 MFMAs runs while the other issues its transpose
+    // reads, its LDS-DMA and the fragment shuffles of its next cluster.  A 64-row step = three phases of two units (kk, ky):
+    //      A: (0,0) (0,1)    reads dz fragments of K half 0 + two band runs, LDS-DMA part 0 of tile s + 2
+    //      B: (0,2) (1,0)    reads dz fragments of K half 1 + two band runs, part 1
+    //      C: (1,1) (1,2)    reads two band runs, part 2, s_waitcnt vmcnt(6): tile s + 1 has landed
+    // phase = [reads ; LDS-DMA ; lgkmcnt(0) ; fragment shuffles ; barrier ; 24 MFMAs ; barrier].  Tile s + 2 goes into the stage tile s - 1
+    // left (its last reads, phase C of step s - 1, were retired in front of that phase's first barrier by BOTH groups before the first
+    // group reaches phase A of step s); tile s + 1 is read one phase after the wait that retires it.
+    // The transpose reads go out as inline asm with immediate offsets from SIX lane address registers (the swizzles of swz16 are XORs
+    // of lane-constant bits: four dz bases -- one per co fragment, the fragment index is XORed with the row -- and two band bases --
+    // the parity of the 8-row block flips with ky and with the third 4-row piece of a run); the compiler hoisted 34 loop-invariant
+    // addresses out of the intrinsic form and spilled 100 registers.
+    unsigned aA[4], aR[2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) aA[mi] = lds0 + (8 * g + rsub) * 256 + csub + (((mi ^ rsub) & 3) << 5) + ((wm ^ (g & 1)) << 7);
+#pragma unroll
+    for (int v = 0; v < 2; ++v) aR[v] = lds0 + (8 * g + rsub) * 128 + csub + (((wn & 1) ^ ((rsub >> 1) & 1)) << 5) + (((wn >> 1) ^ ((g ^ v) & 1)) << 6);
+    auto tr = [](u32x2& d, unsigned addr, auto OFF_) {
+        constexpr int OFF = decltype(OFF_)::value;
+        static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+    };
+    // dz fragments of K half kk (stage byte offset sb is added to the bases once per step)
+    auto rdA4 = [&](u32x4 (&af)[4], unsigned sb, auto KK_) {
+        constexpr int kk = decltype(KK_)::value;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            u32x2 lo, hi;
+            tr(lo, aA[mi] + sb, pipe::IC<kk * 8192>{}); tr(hi, aA[mi] + sb, pipe::IC<kk * 8192 + 1024>{});
+            af[mi] = (u32x4){lo.x, lo.y, hi.x, hi.y};
+        }
+    };
+    auto rdRunA = [&](Run& r, unsigned sb, auto KK_, auto KY_) {
+        constexpr int kk = decltype(KK_)::value, ky = decltype(KY_)::value;
+        constexpr int base = A_BYTES + (ky * BROWS + 32 * kk) * 128;
+        tr(r.r0, aR[ky & 1] + sb, pipe::IC<base>{}); tr(r.r1, aR[ky & 1] + sb, pipe::IC<base + 512>{}); tr(r.r2, aR[(ky + 1) & 1] + sb, pipe::IC<base + 1024>{});
+    };
+    struct Frag3 { u32x4 b[3]; };
+    auto shuffle = [&](const Run& c) {
+        Frag3 f;
+        f.b[0] = (u32x4){c.r0.x, c.r0.y, c.r1.x, c.r1.y};
+        f.b[1] = (u32x4){__builtin_amdgcn_alignbit(c.r0.y, c.r0.x, 16), __builtin_amdgcn_alignbit(c.r1.x, c.r0.y, 16),
+                         __builtin_amdgcn_alignbit(c.r1.y, c.r1.x, 16), __builtin_amdgcn_alignbit(c.r2.x, c.r1.y, 16)};
+        f.b[2] = (u32x4){c.r0.y, c.r1.x, c.r1.y, c.r2.x};
+        return f;
+    };
+    auto unit = [&](const Frag3& f, const u32x4 (&afk)[4], int ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) mma(f.b[kx], afk[mi], acc[ky * 3 + kx][mi]);
+    };
+    auto sbar = []() { asm volatile("s_barrier" ::: "memory"); };
+    u32x4 af0[4], af1[4];
+    if (nsteps > 0) {
+        ALL9S_PART0(0u); ALL9S_PART1(0u); ALL9S_PART2(0u);
+        ALL9S_PART0((unsigned)STAGE); ALL9S_PART1((unsigned)STAGE); ALL9S_PART2((unsigned)STAGE);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");
+        sbar();
+        if (wm == 1) sbar();                                            // the groups part
+    }
+    unsigned so = 0, no = STAGE, po = 2 * STAGE;
+    int bctr = gs0 % a.tiles_ci;
+    for (int s = 0; s < nsteps; ++s) {
+        const bool bias_step = do_bias && bctr == tile_ci;
+        // ---- phase A
+        {
+            Run r0, r1;
+            rdA4(af0, so, pipe::IC<0>{}); rdRunA(r0, so, pipe::IC<0>{}, pipe::IC<0>{}); rdRunA(r1, so, pipe::IC<0>{}, pipe::IC<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            ALL9S_PART0(po);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const Frag3 f0 = shuffle(r0), f1 = shuffle(r1);
+            __builtin_amdgcn_sched_barrier(0);
+            sbar();
+            __builtin_amdgcn_sched_barrier(0);
+            unit(f0, af0, 0); unit(f1, af0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            sbar();
+        }
+        // ---- phase B
+        {
+            Run r0, r1;
+            rdA4(af1, so, pipe::IC<1>{}); rdRunA(r0, so, pipe::IC<0>{}, pipe::IC<2>{}); rdRunA(r1, so, pipe::IC<1>{}, pipe::IC<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            ALL9S_PART1(po);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const Frag3 f0 = shuffle(r0), f1 = shuffle(r1);
+            __builtin_amdgcn_sched_barrier(0);
+            sbar();
+            __builtin_amdgcn_sched_barrier(0);
+            unit(f0, af0, 2); unit(f1, af1, 0);
+            if (bias_step) {                                            // db partial: sum_q dz[q][co] of this wave's fragment wn, K half 0
+                if (wn == 0) mma(ones, af0[0], bacc); else if (wn == 1) mma(ones, af0[1], bacc); else if (wn == 2) mma(ones, af0[2], bacc); else mma(ones, af0[3], bacc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sbar();
+        }
+        // ---- phase C
+        {
+            Run r0, r1;
+            rdRunA(r0, so, pipe::IC<1>{}, pipe::IC<1>{}); rdRunA(r1, so, pipe::IC<1>{}, pipe::IC<2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            ALL9S_PART2(po);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const Frag3 f0 = shuffle(r0), f1 = shuffle(r1);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS) : "memory");   // all but tile s + 2's six: tile s + 1 has landed (this wave's pieces)
+            sbar();
+            __builtin_amdgcn_sched_barrier(0);
+            unit(f0, af1, 1); unit(f1, af1, 2);
+            if (bias_step) {
+                if (wn == 0) mma(ones, af1[0], bacc); else if (wn == 1) mma(ones, af1[1], bacc); else if (wn == 2) mma(ones, af1[2], bacc); else mma(ones, af1[3], bacc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            sbar();
+        }
+        if (++bctr == a.tiles_ci) bctr = 0;
+        { const unsigned t3 = so; so = no; no = po; po = t3; }
+    }
+#undef ALL9S_PART0
+#undef ALL9S_PART1
+#undef ALL9S_PART2
+    if (nsteps > 0 && wm == 0) sbar();                                  // the groups meet again
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // the over-run tiles land before the workgroup ends
+    {
+        float* P = a.partial + (((long long)split * (a.tiles_co * a.tiles_ci) + t) * 8 + wave) * (36 * 256) + lane * 4;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                *(f32x4*)(P + (tp * 4 + mi) * 256) = acc[tp][mi];
+    }
+    if (do_bias && lane < 16)       // every row of the ones-product holds the column sum
+        a.bpartial[((long long)split * a.tiles_ci + tile_ci) * a.co_pad + tile_co * 128 + wm * 64 + wn * 16 + lane] = bacc.x;
+}
+
 // ------------------------------------------------------------------------------------------------ wide 1x1 layers, round 3: LDS-DMA ring
 // The heads' weight gradients (2048 couts x 512 / 256 input channels) with wgrad_all9_kernel's pipeline: 256(co) x 256(ci)
 // tile, 8 waves as 4(co) x 2(ci) (64 x 128 per wave, 4 x 8 accumulator fragments), 32-row K steps, FOUR 32-KB stages (dz tile +
@@ -1823,9 +2072,14 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
             static DbxDevOnce attr_once; int attr_dev = 0;
             if (attr_once.pending(&attr_dev)) {
                 DBX_HIP(hipFuncSetAttribute((const void*)wgrad_all9_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                DBX_HIP(hipFuncSetAttribute((const void*)wgrad_all9s_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
                 attr_once.mark(attr_dev);
             }
-            hipLaunchKernelGGL((wgrad_all9_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a);
+            // round 5: the same tile with the two wave groups one barrier apart (DBX_WGRAD_STAG=0: the lock-step kernel of round 3)
+            static int stag = -1;
+            if (stag < 0) { const char* e = getenv("DBX_WGRAD_STAG"); stag = e ? atoi(e) : 1; }
+            if (stag) hipLaunchKernelGGL((wgrad_all9s_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a);
+            else hipLaunchKernelGGL((wgrad_all9_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(512), smem, s, a);
         }
     } else if (p.c8) {
         if constexpr (sizeof(T) == 2) hipLaunchKernelGGL((wgrad3x3_c8_kernel<T>), dim3(p.splits), dim3(256), 0, s, a);

@@ -294,3 +294,114 @@ __device__ __forceinline__ void for_chunks(Acc<MF>& acc, const Lanes<MF>& L, FIN
     }
 }
 }  // namespace p8
+
+// ------------------------------------------------------------------------------------------------ 512 (m) x 128 (n) variant
+// The same phase program for layers with 128 couts: FOUR m halves of 128 rows and ONE n half, K tile 64.  A wave owns 64 rows of each m
+// half and 32 n (wave (wr, wc): m = 128 mh + 64 wr + .., n = 32 wc + ..): phase p of a K tile reads A[p - 1] (8 x ds_read_b128; phase 1
+// also B, 4 reads, first) and runs the 16 MFMAs of C quadrant p - 1 against the B fragments phase 1 left in registers.
+// LDS: 2 K tiles x (A[0..3] + B) x 16 KB = 160 KB (all of it).  Five half-tiles per K tile go out in the order B, A0, A1, A2, A3 over four
+// phases -- each one re-staged as early as its last read allows: of K tile kt (parity d) phase 1 stages A2 of kt + 1, phase 2 A3 of kt + 1 AND
+// B of kt + 2, phase 3 A0 of kt + 2, phase 4 A1 of kt + 2 -- so that phase 4's vmcnt(6) again leaves exactly the three youngest half-tiles
+// in flight and retires the whole next K tile.
+namespace p8w {
+using p8::barrier; using p8::glds; using p8::lds_read; using p8::Mma16;
+constexpr int LDS_BYTES = 163840;
+constexpr int A_OFF(int d, int mh) { return (d * 4 + mh) * 16384; }      // A region [0, 128 KB)
+constexpr int B_OFF(int d) { return 131072 + d * 16384; }                // B region [128 KB, 160 KB)
+
+// v[mh][mi][ni]: n = 32 wc + 16 ni + 4 (lane >> 4) + j,  m = 128 mh + 64 wr + 16 mi + (lane & 15)
+struct Acc { f32x4 v[4][4][2]; };
+__device__ __forceinline__ void zero(Acc& a) {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) (&a.v[0][0][0])[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+struct Lanes {
+    unsigned ra[2][2];       // [d][kk]: A read bases (the second K tile's half-tiles lie beyond the 64-KB reach of a ds_read offset)
+    unsigned rb[2];          // [kk]
+    unsigned dst;            // LDS-DMA destination of this wave's piece 0 at LDS offset 0
+    int wave, wr, wc, lane;
+};
+__device__ __forceinline__ Lanes lanes(const char* smem) {
+    Lanes L;
+    const int tid = threadIdx.x;
+    L.lane = tid & 63;
+    L.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    L.wr = L.wave >> 2; L.wc = L.wave & 3;
+    const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+    L.dst = lds0 + L.wave * 1024;
+    const int l15 = L.lane & 15, g = L.lane >> 4, s = (l15 >> 1) & 7;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const unsigned a0 = lds0 + (L.wr * 64 + l15) * 128 + (((kk * 4 + g) ^ s) << 4);
+        L.ra[0][kk] = a0; L.ra[1][kk] = a0 + 65536;
+        L.rb[kk] = lds0 + 131072 + (L.wc * 32 + l15) * 128 + (((kk * 4 + g) ^ s) << 4);
+    }
+    return L;
+}
+// stA(kt, mh, dst) / stB(kt, dst): as p8 (two LDS-DMA per call); kt may run past nkt by up to 2
+template <typename SA, typename SB>
+__device__ __forceinline__ void prologue(const Lanes& L, SA stA, SB stB) {
+    stB(0, L.dst + B_OFF(0));
+#pragma unroll
+    for (int mh = 0; mh < 4; ++mh) stA(0, mh, L.dst + A_OFF(0, mh));
+    stB(1, L.dst + B_OFF(1)); stA(1, 0, L.dst + A_OFF(1, 0)); stA(1, 1, L.dst + A_OFF(1, 1));
+}
+__device__ __forceinline__ void start() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); barrier(); }
+__device__ __forceinline__ void tile_begin(const Lanes& L) { if (L.wr == 1) barrier(); }
+__device__ __forceinline__ void tile_end(const Lanes& L) { if (L.wr == 0) barrier(); }
+__device__ __forceinline__ void finish() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
+// MI2 / MI3: 16-row fragments per wave in m halves 2 and 3 (4, or 3: a 480- / 448-row tile; halves 0 and 1 are always full)
+template <typename T, int MI2, int MI3, typename SA, typename SB>
+__device__ __forceinline__ void ktiles(Acc& acc, const Lanes& L, int nkt, SA stA, SB stB) {
+    static_assert(MI2 >= 3 && MI2 <= 4 && MI3 >= 3 && MI3 <= MI2, "tile height");
+    u32x4 af[8], bf[4];
+    auto readA = [&](auto D_, auto H_) {
+        constexpr int d = decltype(D_)::value, mh = decltype(H_)::value, base = A_OFF(d, mh) - d * 65536;
+        constexpr int NI = mh == 2 ? MI2 : (mh == 3 ? MI3 : 4);
+        lds_read<base + 0 * 2048>(af[0], L.ra[d][0]); lds_read<base + 1 * 2048>(af[1], L.ra[d][0]); lds_read<base + 2 * 2048>(af[2], L.ra[d][0]);
+        if constexpr (NI > 3) lds_read<base + 3 * 2048>(af[3], L.ra[d][0]);
+        lds_read<base + 0 * 2048>(af[4], L.ra[d][1]); lds_read<base + 1 * 2048>(af[5], L.ra[d][1]); lds_read<base + 2 * 2048>(af[6], L.ra[d][1]);
+        if constexpr (NI > 3) lds_read<base + 3 * 2048>(af[7], L.ra[d][1]);
+    };
+    auto readB = [&](auto D_) {
+        constexpr int base = decltype(D_)::value * 16384;
+        lds_read<base>(bf[0], L.rb[0]); lds_read<base + 2048>(bf[1], L.rb[0]);
+        lds_read<base>(bf[2], L.rb[1]); lds_read<base + 2048>(bf[3], L.rb[1]);
+    };
+    auto cluster = [&](auto MH_) {
+        constexpr int mh = decltype(MH_)::value;
+        constexpr int NI = mh == 2 ? MI2 : (mh == 3 ? MI3 : 4);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < NI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) Mma16<T>::run(bf[kk * 2 + ni], af[kk * 4 + mi], acc.v[mh][mi][ni]);
+    };
+    auto phase = [&](auto P_, auto D_, int kt) {
+        constexpr int P = decltype(P_)::value, d = decltype(D_)::value;
+        using pipe::IC;
+        if constexpr (P == 1) { readB(IC<d>{}); __builtin_amdgcn_sched_barrier(0); }
+        readA(IC<d>{}, IC<P - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == 1) stA(kt + 1, 2, L.dst + A_OFF(d ^ 1, 2));
+        if constexpr (P == 2) { stA(kt + 1, 3, L.dst + A_OFF(d ^ 1, 3)); stB(kt + 2, L.dst + B_OFF(d)); }
+        if constexpr (P == 3) stA(kt + 2, 0, L.dst + A_OFF(d, 0));
+        if constexpr (P == 4) stA(kt + 2, 1, L.dst + A_OFF(d, 1));
+        if constexpr (P == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (P == 1) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        cluster(IC<P - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        barrier();
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        using pipe::IC;
+        phase(IC<1>{}, IC<0>{}, kt); phase(IC<2>{}, IC<0>{}, kt); phase(IC<3>{}, IC<0>{}, kt); phase(IC<4>{}, IC<0>{}, kt);
+        phase(IC<1>{}, IC<1>{}, kt + 1); phase(IC<2>{}, IC<1>{}, kt + 1); phase(IC<3>{}, IC<1>{}, kt + 1); phase(IC<4>{}, IC<1>{}, kt + 1);
+    }
+}
+}  // namespace p8w

@@ -88,6 +88,11 @@ P8_CASES = [  # n, h, w, cin, cout, epilogue kind: the 8-phase implicit-GEMM ker
     (64, 30, 30, 512, 512, 'relu'),     # conv4 at batch 64: two cout tiles (an XCD keeps to one), 256 tiles of 7 / 8 units
     (12, 50, 90, 128, 256, 'plain'),    # W != H, a ragged last unit (54000 pixels)
     (33, 30, 30, 256, 512, 'gate'),     # 29700 pixels x 2 cout tiles: ragged last unit, image seams inside tiles
+    # 128-cout layers: 512-pixel x 128-cout tiles of 14 / 15 / 16 units (conv3x3_p8w_kernel)
+    (8, 120, 120, 128, 128, 'relu'),    # 225 tiles of 16 units
+    (10, 120, 120, 128, 128, 'gate'),   # 282 tiles of 15 / 16 units, a second tile per workgroup, channel-slice views
+    (64, 60, 60, 256, 128, 'gate'),     # conv3_1's data gradient at batch 64: 512 tiles of 14 / 15 units
+    (9, 100, 130, 128, 128, 'plain'),   # W != H, ragged last unit
 ]
 
 
@@ -128,7 +133,7 @@ def test_conv_p8_kernel(case, dtn):
         return fy, ty, View(yv_all.ptr, n, h, w, 1, yv_all.ld, yo, co)
     fy, ty, yv = out_view()
     check(L.dbx_conv_plan(C.byref(d), C.byref(xv), C.byref(yv), C.byref(plan)))
-    assert plan.kernel == _lib.K_P8 and b'conv3x3_p8_kernel' in plan.name and not plan.w_frag, plan.name
+    assert plan.kernel == _lib.K_P8 and (b'conv3x3_p8w_kernel' if co == 128 else b'conv3x3_p8_kernel') in plan.name and not plan.w_frag, plan.name
     wp = pack(L, dt, wt, ci, co)
     outs, keep = [], []
     for _ in range(2):
