@@ -35,8 +35,8 @@ FWD_GFLOP = {'DenseBox': 41.98, 'DenseBoxLM': 44.95, 'DenseBoxLMLOC': 47.81}
 STEP_GFLOP = {'DenseBox': 125.7, 'DenseBoxLM': 134.6, 'DenseBoxLMLOC': 143.2}
 MFMA_PEAK_TF = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}     # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = 'r04_pmc_traffic.json'
-ERR_FILES = ('r04_lowprec_errors.json', 'r03_lowprec_errors.json')
+PMC_FILE = 'r05_pmc_traffic.json'
+ERR_FILES = ('r05_lowprec_errors.json', 'r04_lowprec_errors.json', 'r03_lowprec_errors.json')
 
 
 def conv_flops(eng_calls):
@@ -163,7 +163,7 @@ def pmc_traffic(family):
     """HBM bytes per launch of a kernel family from the committed PMC summary (profiles/r03_pmc_traffic.json: separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, FETCH_SIZE doubled per the gfx950 correction
     in MI355X_MICROARCH.md; tools/pmc_traffic.py stamps it with csrc_hash()).  None when the summary is absent, was
-    collected on other kernel sources, does not list the family, or lists more than one symbol that fits it."""
+    collected on other kernel sources, or does not list the family."""
     path = os.path.join(ROOT, 'profiles', PMC_FILE)
     if not os.path.exists(path):
         return None
@@ -178,7 +178,12 @@ def pmc_traffic(family):
     code = {'bf16': 'DF16b', 'f16': 'DF16_', 'f32': 'f'}[m.group(2)]
     want = '%sI%s%s' % (m.group(1), code, ''.join('Li%sE' % v for v in m.group(3).split(',') if v))
     hits = [v for k, v in doc.get('kernels', {}).items() if want in k]
-    return round(hits[0]['hbm_bytes_per_launch']) if len(hits) == 1 else None
+    if not hits:
+        return None
+    # (a family may be several instantiations of one template behind the named arguments -- the 8-phase kernel's forward and gated
+    #  data-gradient epilogues: launch-weighted mean)
+    nl = sum(v['launches'] for v in hits)
+    return round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hits) / nl) if nl else None
 
 
 def inference(kind, dev):

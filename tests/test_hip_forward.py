@@ -1,14 +1,13 @@
 """GPU parity: HIP forward (through the C ABI) vs the CPU oracle and the reference-captured fixtures.
 
-Tolerances (outputs are O(1); loc-type outputs O(10)):
-  f32  : |err| <= 1e-4 * max(1, |ref|)   exact-fp32 MFMA, only summation order differs
-  f16  : fp16 activation rounding accumulated over 13 layers.  Achieved (profiles/r03_lowprec_errors.json, tools/gpu_lowprec_err.py):
-         bbox / landmark-offset maps 0.7-0.8e-3, score / heat maps 1.4-1.9e-3, the refined score of DenseBoxLMLOC 3.1e-3 of max|ref|
-         (its INPUTS, the f16 head outputs, carry 1.5-1.9e-3 and its three convs amplify that: running the branch itself in fp32 was
-         tried in round 3 and left it where it was; DenseBoxLM's refined score is 1.5e-3).  MAX error bar = achieved + 20 %:
-         3.8e-3 * max|ref|; RMS error bar 1e-3 (north_star's figure; achieved 2-9e-4 on every map)
-  bf16 : 8x coarser mantissa: achieved 0.6-1.6e-2, refined score 1.6-1.7e-2 (2.4-2.7e-2 before its eval-mode branch became one fp32 kernel)
-         -> max bar 3e-2, RMS bar 8e-3 (achieved <= 5.5e-3)
+Tolerances (outputs are O(1); loc-type outputs O(10)); error = max |hip - ref| / max(1, max|ref|) per output map:
+  f32  : 1e-4                       exact-fp32 MFMA, only summation order differs (achieved <= 8e-6)
+  f16  : PER MAP (MAP_TOL below, from profiles/r04_lowprec_errors.json = tools/gpu_lowprec_err.py on these fixtures): north_star's 1e-3 where
+         the map meets it (the bbox maps: 0.74e-3 achieved), achieved + 20 % elsewhere (score / heat / offset maps 1.2-1.8e-3, the refined
+         score of DenseBoxLMLOC 3.0e-3: fp16 activation rounding accumulated over 13 layers; its INPUTS, the f16 head outputs, carry
+         1.5-1.9e-3 and its three convs amplify that) -- a regression of a map that meets 1e-3 fails at 1e-3, not at the worst map's bar.
+         RMS error bar 1e-3 on every map (north_star's figure; achieved 2-9e-4)
+  bf16 : 8x coarser mantissa: per map, achieved + 20 % (0.57-1.8e-2); RMS bar 8e-3 (achieved <= 5.5e-3)
 """
 import numpy as np
 import pytest
@@ -21,7 +20,13 @@ import densebox_amd as D
 pytestmark = pytest.mark.gpu
 
 KINDS = ['DenseBox', 'DenseBoxLM', 'DenseBoxLMLOC']
-TOL = {'f32': 1e-4, 'f16': 3.8e-3, 'bf16': 3e-2}
+TOL = {'f32': 1e-4, 'f16': 3.8e-3, 'bf16': 3e-2}            # flat bars: intermediate taps, odd sizes, whole images
+# per output map of the 240 x 240 fixtures: north_star's 1e-3 where achieved, else achieved (r04_lowprec_errors.json) + 20 %
+MAP_TOL = {
+    ('DenseBox', 'f16'): [2.19e-3, 1.0e-3], ('DenseBox', 'bf16'): [1.25e-2, 6.8e-3],
+    ('DenseBoxLM', 'f16'): [2.19e-3, 1.0e-3, 1.61e-3, 1.46e-3], ('DenseBoxLM', 'bf16'): [1.25e-2, 6.8e-3, 1.32e-2, 7.6e-3],
+    ('DenseBoxLMLOC', 'f16'): [2.19e-3, 3.59e-3, 1.0e-3, 1.71e-3, 2.13e-3], ('DenseBoxLMLOC', 'bf16'): [1.25e-2, 2.12e-2, 6.8e-3, 1.15e-2, 1.33e-2],
+}
 RMS_TOL = {'f32': 2e-5, 'f16': 1e-3, 'bf16': 8e-3}        # per-map RMS error / max(1, max|ref|)
 
 
@@ -55,7 +60,8 @@ def test_forward_vs_reference_fixture(golden, kind, dtype):
     assert len(outs) == sum(1 for k in g.files if k.startswith('out240_'))
     for i, o in enumerate(outs):
         assert o.dtype == torch.float32 and o.is_contiguous()
-        _close(o, g['out240_%d' % i], TOL[dtype], '%s/%s out %d' % (kind, dtype, i), RMS_TOL[dtype])
+        tol = TOL[dtype] if dtype == 'f32' else MAP_TOL[(kind, dtype)][i]
+        _close(o, g['out240_%d' % i], tol, '%s/%s out %d' % (kind, dtype, i), RMS_TOL[dtype])
     # intermediate taps (first conv + first pool) pin the layer kernels individually
     eng = net.engine()
     a11 = eng.read_activation('a11')[0, ::8, ::6, ::6]
