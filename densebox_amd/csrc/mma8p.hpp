@@ -38,6 +38,8 @@ constexpr int LDS_BYTES = 131072;
 constexpr int FL_PRIO = 1;        // s_setprio 1 around the MFMA cluster
 constexpr int FL_STAGGER = 2;     // the two wave groups run one barrier apart
 constexpr int FL_TSYNC = 8;       // persistent kernels: the wave groups meet at every tile seam (their epilogues run side by side) and part again behind it
+constexpr int FL_NODMA = 16;      // probe ablation (wrong results): no LDS-DMA inside the K loop
+constexpr int FL_NOREAD = 32;     // probe ablation (wrong results): no fragment reads inside the K loop
 constexpr int FL_SAFE = 4;        // debugging: every phase drains vmcnt / lgkmcnt in front of its first barrier (separates layout bugs from ordering bugs)
 
 template <int MF> struct Acc;
@@ -209,17 +211,18 @@ __device__ __forceinline__ void ktiles(Acc<MF>& acc, const Lanes<MF>& L, int nkt
     auto phase = [&](auto P_, auto D_, int kt) {
         constexpr int P = decltype(P_)::value, d = decltype(D_)::value;
         using pipe::IC;
-        if constexpr (P == 1) { readB(IC<d>{}, IC<0>{}); __builtin_amdgcn_sched_barrier(0); readA(IC<d>{}, IC<0>{}); }
-        if constexpr (P == 2) readB(IC<d>{}, IC<1>{});
-        if constexpr (P == 3) readA(IC<d>{}, IC<1>{});
+        constexpr bool RD = !(FLAGS & FL_NOREAD), DMA = !(FLAGS & FL_NODMA);
+        if constexpr (P == 1 && RD) { readB(IC<d>{}, IC<0>{}); __builtin_amdgcn_sched_barrier(0); readA(IC<d>{}, IC<0>{}); }
+        if constexpr (P == 2 && RD) readB(IC<d>{}, IC<1>{});
+        if constexpr (P == 3 && RD) readA(IC<d>{}, IC<1>{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (P == 1) stA(kt + 1, 1, L.dst + ((d ^ 1) * 2 + 1) * 16384);
-        if constexpr (P == 2) stB(kt + 2, 0, L.dst + 65536 + (d * 2 + 0) * 16384);
-        if constexpr (P == 3) stA(kt + 2, 0, L.dst + (d * 2 + 0) * 16384);
-        if constexpr (P == 4) stB(kt + 2, 1, L.dst + 65536 + (d * 2 + 1) * 16384);
+        if constexpr (P == 1 && DMA) stA(kt + 1, 1, L.dst + ((d ^ 1) * 2 + 1) * 16384);
+        if constexpr (P == 2 && DMA) stB(kt + 2, 0, L.dst + 65536 + (d * 2 + 0) * 16384);
+        if constexpr (P == 3 && DMA) stA(kt + 2, 0, L.dst + (d * 2 + 0) * 16384);
+        if constexpr (P == 4 && DMA) stB(kt + 2, 1, L.dst + 65536 + (d * 2 + 1) * 16384);
         if constexpr (SAFE) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else if constexpr (P == 4) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if constexpr (P == 1) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else if constexpr (P == 4 && DMA) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (P == 1 && RD) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
         barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -239,6 +242,67 @@ __device__ __forceinline__ void ktiles(Acc<MF>& acc, const Lanes<MF>& L, int nkt
     }
 }
 
+// Probe variant (tools/probe_gemm_8phase.hip): TWO phases per K tile, 32 MFMAs per cluster -- half the barriers.  Phase X reads B[0], B[1], A[0]
+// (16 reads) and runs quadrants (0,0), (0,1); phase Y reads A[1] and runs (1,1), (1,0).  Every phase retires its reads in front of its
+// first barrier, so a half-tile may be re-staged one phase after its last read: Y of K tile kt stages B[0], B[1] of kt + 2, X of kt + 1
+// stages A[0], A[1] of kt + 2; the wait in Y (at most the 4 LDS-DMA it has just issued in flight) retires the whole next K tile.
+// Prologue: K tile 0 and B[0], B[1] of K tile 1 (then vmcnt(4)).
+template <typename T, int FLAGS, typename SA, typename SB>
+__device__ __forceinline__ void ktiles4(Acc<16>& acc, const Lanes<16>& L, int nkt, SA stA, SB stB) {
+    u32x4 af[8], bf[2][4];
+    auto rdA = [&](auto D_, auto H_) {
+        constexpr int base = (decltype(D_)::value * 2 + decltype(H_)::value) * 16384;
+        lds_read<base + 0 * 2048>(af[0], L.ra[0]); lds_read<base + 1 * 2048>(af[1], L.ra[0]); lds_read<base + 2 * 2048>(af[2], L.ra[0]); lds_read<base + 3 * 2048>(af[3], L.ra[0]);
+        lds_read<base + 0 * 2048>(af[4], L.ra[1]); lds_read<base + 1 * 2048>(af[5], L.ra[1]); lds_read<base + 2 * 2048>(af[6], L.ra[1]); lds_read<base + 3 * 2048>(af[7], L.ra[1]);
+    };
+    auto rdB = [&](auto D_, auto H_) {
+        constexpr int nh = decltype(H_)::value, base = (decltype(D_)::value * 2 + nh) * 16384;
+        lds_read<base>(bf[nh][0], L.rb[0]); lds_read<base + 2048>(bf[nh][1], L.rb[0]);
+        lds_read<base>(bf[nh][2], L.rb[1]); lds_read<base + 2048>(bf[nh][3], L.rb[1]);
+    };
+    auto cluster = [&](auto MH_, auto NH_) {
+        constexpr int mh = decltype(MH_)::value, nh = decltype(NH_)::value;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) Mma16<T>::run(bf[nh][kk * 2 + ni], af[kk * 4 + mi], acc.v[mh][nh][mi][ni]);
+    };
+    auto phase = [&](auto P_, auto D_, int kt) {
+        constexpr int P = decltype(P_)::value, d = decltype(D_)::value;
+        using pipe::IC;
+        if constexpr (P == 0) { rdB(IC<d>{}, IC<0>{}); rdB(IC<d>{}, IC<1>{}); rdA(IC<d>{}, IC<0>{}); }
+        else rdA(IC<d>{}, IC<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == 0) { stA(kt + 1, 0, L.dst + ((d ^ 1) * 2 + 0) * 16384); stA(kt + 1, 1, L.dst + ((d ^ 1) * 2 + 1) * 16384); }
+        else { stB(kt + 2, 0, L.dst + 65536 + (d * 2 + 0) * 16384); stB(kt + 2, 1, L.dst + 65536 + (d * 2 + 1) * 16384); }
+        if constexpr (P == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (P == 0) { cluster(IC<0>{}, IC<0>{}); cluster(IC<0>{}, IC<1>{}); }
+        else { cluster(IC<1>{}, IC<1>{}); cluster(IC<1>{}, IC<0>{}); }
+        __builtin_amdgcn_sched_barrier(0);
+        barrier();
+    };
+    for (int kt = 0; kt < nkt; kt += 2) {
+        using pipe::IC;
+        phase(IC<0>{}, IC<0>{}, kt); phase(IC<1>{}, IC<0>{}, kt);
+        phase(IC<0>{}, IC<1>{}, kt + 1); phase(IC<1>{}, IC<1>{}, kt + 1);
+    }
+}
+template <typename SA, typename SB>
+__device__ __forceinline__ void prologue4(const Lanes<16>& L, SA stA, SB stB) {
+    stB(0, 0, L.dst + 65536); stB(0, 1, L.dst + 65536 + 16384); stA(0, 0, L.dst); stA(0, 1, L.dst + 16384);
+    stB(1, 0, L.dst + 65536 + 32768); stB(1, 1, L.dst + 65536 + 49152);
+}
+template <int FLAGS>
+__device__ __forceinline__ void start4(const Lanes<16>& L) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    barrier();
+    if ((FLAGS & FL_STAGGER) && L.wr == 1) barrier();
+}
 }  // namespace p8
 
 namespace p8 {

@@ -14,7 +14,8 @@ lib.p8_gemm.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_vo
                         ctypes.c_int, ctypes.c_void_p]
 DT = {torch.float16: 0, torch.bfloat16: 1}          # DBX_F16 / DBX_BF16 (include/densebox_hip.h)
 VAR = {0: '16x16x32 prio+stagger', 1: '32x32x16 prio+stagger', 2: '16x16x32 stagger, no prio', 3: '16x16x32 prio, no stagger',
-       4: '16x16x32 SAFE', 5: '32x32x16 stagger, no prio', 6: '32x32x16 SAFE'}
+       4: '16x16x32 SAFE', 5: '32x32x16 stagger, no prio', 6: '32x32x16 SAFE', 7: '16x16x32 stagger, 2 phases per K tile'}
+ABL = {8: 'v2 without LDS-DMA in the loop (timing only)', 9: 'v2 without fragment reads (timing only)', 10: 'v2 with neither (timing only)'}
 out_lines = []
 
 
@@ -99,7 +100,7 @@ def bench(M, N, K, dtype, kinds=('rand', 'relu', 'zero'), variants=(0, 1, 2, 3, 
         fns = [('hipBLASLt torch.mm', lambda: torch.mm(A, Bt, out=C))]
         for v in variants:
             for gm in gms:
-                fns.append(('v%d %s gm=%d' % (v, VAR[v], gm), (lambda v=v, gm=gm: gemm(v, A, B, C, gm))))
+                fns.append(('v%d %s gm=%d' % (v, VAR.get(v) or ABL[v], gm), (lambda v=v, gm=gm: gemm(v, A, B, C, gm))))
         for _, f in fns:
             f()
         torch.cuda.synchronize()
@@ -116,6 +117,14 @@ def main():
     say('device: %s' % torch.cuda.get_device_name(0))
     ok = check()
     say('correctness: %s' % ('ALL OK' if ok else 'FAILURES ABOVE'))
+    if len(sys.argv) > 2 and sys.argv[2] == 'ablate':
+        # what bounds the phase program: clusters of 32 MFMAs (half the barriers), and the loop without its LDS-DMA / fragment reads
+        bench(4096, 4096, 4096, torch.float16, kinds=('rand',), variants=(2, 7, 8, 9, 10), rounds=3)
+        bench(8192, 8192, 8192, torch.float16, kinds=('rand',), variants=(2, 7, 8, 9, 10), rounds=2)
+        bench(64 * 30 * 30, 512, 4608, torch.float16, kinds=('relu',), variants=(2, 7, 8, 9, 10), rounds=3)
+        with open(sys.argv[1], 'w') as f:
+            f.write('\n'.join(out_lines) + '\n')
+        return
     bench(4096, 4096, 4096, torch.float16)
     bench(4096, 4096, 4096, torch.bfloat16, kinds=('rand',))
     bench(8192, 8192, 8192, torch.float16, rounds=2)

@@ -48,10 +48,19 @@ __global__ __launch_bounds__(512, 1) void gemm8p_kernel(const GemmArgs a) {
         const char* b = Bb + (size_t)(nh * 128) * lda + (size_t)kt * 128;
         p8::glds(b, vo, dst); p8::glds(b + 64 * lda, vo, dst + 8192);
     };
-    p8::prologue<MF>(L, stA, stB);
-    p8::start<FLAGS>(L);
-    p8::ktiles<T, MF, FLAGS>(acc, L, nkt, stA, stB);
-    p8::finish<FLAGS>(L);
+    if constexpr (FLAGS & 64) {           // the two-phases-per-K-tile variant (32 MFMAs per cluster)
+        if constexpr (MF == 16) {
+            p8::prologue4(L, stA, stB);
+            p8::start4<FLAGS>(L);
+            p8::ktiles4<T, FLAGS>(acc, L, nkt, stA, stB);
+            p8::finish<FLAGS>(L);
+        }
+    } else {
+        p8::prologue<MF>(L, stA, stB);
+        p8::start<FLAGS>(L);
+        p8::ktiles<T, MF, FLAGS>(acc, L, nkt, stA, stB);
+        p8::finish<FLAGS>(L);
+    }
     T* const C = (T*)a.C;
     p8::for_chunks<T, MF>(acc, L, [](int, int, int, f32x4&) {},
         [&](int mh, int nh, int m, int n, const u32x4& o) { *(u32x4*)(C + (size_t)(m0 + mh * 128 + m) * a.N + n0 + nh * 128 + n) = o; });
@@ -69,7 +78,8 @@ static int launch(const GemmArgs& a, hipStream_t st) {
 }
 
 // variant: 0 = 16x16x32 prio + stagger (the template), 1 = 32x32x16 prio + stagger, 2 = 16 stagger without prio, 3 = 16 prio without stagger,
-//          4 = 16 SAFE (drained waits, no stagger), 5 = 32 stagger without prio, 6 = 32 SAFE
+//          4 = 16 SAFE (drained waits, no stagger), 5 = 32 stagger without prio, 6 = 32 SAFE, 7 = 16 stagger, two phases per K tile (32-MFMA clusters),
+//          8 / 9 / 10 = ablations of variant 2 (wrong results: timing only): no LDS-DMA in the loop / no fragment reads / neither
 extern "C" int p8_gemm(int variant, int dtype, const void* A, const void* B, void* C, int M, int N, int K, int gm, void* stream) {
     if (M % 256 || N % 256 || K % 128 || K < 128) return -1;
     GemmArgs a;
@@ -86,6 +96,10 @@ extern "C" int p8_gemm(int variant, int dtype, const void* A, const void* B, voi
         case 4: return launch<T, 16, FL_SAFE>(a, st);                                \
         case 5: return launch<T, 32, FL_STAGGER>(a, st);                             \
         case 6: return launch<T, 32, FL_SAFE>(a, st);                                \
+        case 7: return launch<T, 16, FL_STAGGER | 64>(a, st);                        \
+        case 8: return launch<T, 16, FL_STAGGER | FL_NODMA>(a, st);                  \
+        case 9: return launch<T, 16, FL_STAGGER | FL_NOREAD>(a, st);                 \
+        case 10: return launch<T, 16, FL_STAGGER | FL_NODMA | FL_NOREAD>(a, st);     \
         default: return -4;                                                          \
     }
     if (dtype == DBX_F16) { V(_Float16) }
