@@ -33,7 +33,36 @@ struct P8Args {
     int nkt;             // K tiles: taps * cin / 64 (even)
     int HW, W;           // output pixels per image / per row
     float inv_HW, inv_W;
+    unsigned long long* stamp;   // lab builds (-DDBX_P8_STAMP): {first workgroup in, last workgroup out} of this launch in s_memrealtime ticks (10 ns), else null
 };
+
+#ifdef DBX_P8_STAMP
+// Launch-boundary measurement WITHOUT a profiler (tools/gpu_p8_stamps.py): every launch of the 8-phase kernels stamps the 100-MHz real-time
+// counter when its first workgroup starts and when its last one ends; dbx_lab_p8_stamps copies the table out.
+static unsigned long long* g_p8_stamps = nullptr;
+static int g_p8_stamp_n = 0;
+constexpr int P8_STAMP_MAX = 4096;
+static unsigned long long* p8_next_stamp() {
+    if (!g_p8_stamps) {
+        if (hipMalloc(&g_p8_stamps, sizeof(unsigned long long) * 2 * P8_STAMP_MAX) != hipSuccess) return nullptr;
+        std::vector<unsigned long long> init(2 * P8_STAMP_MAX);
+        for (int i = 0; i < P8_STAMP_MAX; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
+        (void)hipMemcpy(g_p8_stamps, init.data(), sizeof(unsigned long long) * 2 * P8_STAMP_MAX, hipMemcpyHostToDevice);
+    }
+    if (g_p8_stamp_n >= P8_STAMP_MAX) return nullptr;
+    return g_p8_stamps + 2 * (g_p8_stamp_n++);
+}
+extern "C" int dbx_lab_p8_stamps(unsigned long long* out, int max_n) {
+    const int n = g_p8_stamp_n < max_n ? g_p8_stamp_n : max_n;
+    if (n > 0 && hipMemcpy(out, g_p8_stamps, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#define P8_STAMP_IN(t) do { if ((t).stamp && threadIdx.x == 0) atomicMin((t).stamp, wall_clock64()); } while (0)
+#define P8_STAMP_OUT(t) do { if ((t).stamp && threadIdx.x == 0) atomicMax((t).stamp + 1, wall_clock64()); } while (0)
+#else
+#define P8_STAMP_IN(t) do { } while (0)
+#define P8_STAMP_OUT(t) do { } while (0)
+#endif
 
 // EPIK 0: bias and / or ReLU by the arguments' flags; EPIK 2: the ReLU gate of the data gradients, no bias (its own instantiation: the gate
 // chunks of a whole tile are in flight together and want the registers the bias would hold).  EPIK 1 (1x1 only): the heads' forward -- bias + hash dropout
@@ -53,6 +82,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
     constexpr int NTAPS = KS * KS;
     static_assert(EPIK != 1 || KS == 1, "the heads epilogue belongs to the 1x1 instantiation");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    P8_STAMP_IN(t);
     const p8::Lanes<16> L = p8::lanes<16>(smem);
     const int lane = L.lane, wave = L.wave;
     const int pix_bytes = a.x_ld * ES;
@@ -71,7 +101,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
     } else {
         item = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     }
-    if (item >= t.items) return;
+    if (item >= t.items) { P8_STAMP_OUT(t); return; }
 
     struct Tile { int p0, nf, n0; };
     auto tile_of = [&](int it) {
@@ -150,8 +180,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
     f32x4 bias[2][2];
     int bias_n0 = -1;
 
-    p8::prologue<16>(L, stA, stB);
-    p8::start<FLAGS>(L);
+    if constexpr (FLAGS & p8::FL_P4) { p8::prologue4(L, stA, stB); p8::start4<FLAGS>(L); }
+    else { p8::prologue<16>(L, stA, stB); p8::start<FLAGS>(L); }
     p8::Acc<16> acc;
     for (;;) {
         const int nxt_item = item + G;
@@ -170,7 +200,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
         auto body = [&](auto MI1_) {
             constexpr int MI1 = decltype(MI1_)::value;
             p8::tile_begin<FLAGS>(L);
-            p8::ktiles<T, 16, FLAGS, MI1>(acc, L, nkt, stA, stB);
+            if constexpr (FLAGS & p8::FL_P4) p8::ktiles4<T, FLAGS, MI1>(acc, L, nkt, stA, stB);
+            else p8::ktiles<T, 16, FLAGS, MI1>(acc, L, nkt, stA, stB);
             p8::tile_end<FLAGS>(L);
             if constexpr (EPIK == 1) {
                 // ---- heads forward: 2 (acc + bias) behind the keep bits, rounded, stored; the second convs on the stored chunks
@@ -294,6 +325,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
             for (int j = 0; j < 2; ++j) vcur[mh][j] = vnxt[mh][j];
     }
     p8::finish<FLAGS>(L);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P8_STAMP_OUT(t);
 }
 
 // tile schedule: units of 32 pixels, tiles of 7 or 8 units, their number rounded up to fill whole rounds of CUs
@@ -310,17 +343,20 @@ static inline bool p8_schedule(long long M, int ntile_n, int ncu, P8Args& t) {
     return t.base == 8 ? t.extra == 0 : t.base == 7;                    // the kernel has 7- and 8-unit tiles
 }
 
-template <typename T, int KS, int EPIK = 0, int FLAGS = p8::FL_STAGGER | p8::FL_TSYNC>
+// Default phase program: the 3x3 layers run TWO phases per K tile (clusters of 32 MFMAs, p8::ktiles4: half the barriers -- conv4_2 forward
+// 187 -> 182 us = 1496 TFLOP/s, the gated data gradients -4 %, step -0.7 % over three alternating pairs), the 1x1 GEMMs keep four phases of 16
+// (with two phases the heads forward measured 848 -> 864 us)
+template <int KS> constexpr int p8_default_flags() { return p8::FL_STAGGER | p8::FL_TSYNC | (KS == 3 ? p8::FL_P4 : 0); }
+template <typename T, int KS, int EPIK = 0, int FLAGS = p8_default_flags<KS>()>
 static int launch_conv_p8(const ConvArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
 #ifdef DBX_P8_AB
-        // same-box A/B (tools/build_variant.sh -DDBX_P8_AB): DBX_P8_TSYNC=0 runs the instantiation whose wave groups stay one phase apart across
-        // the tile seams (their epilogues then run one after the other).  Measured: the groups meeting at every seam is 0.8 % of the step faster
-        // (8.987 -> 8.917 ms, three alternating pairs; heads forward 879 -> 851 us, the gated data gradients -3 %)
-        if constexpr (FLAGS == (p8::FL_STAGGER | p8::FL_TSYNC)) {
-            static int tsync = -1;
-            if (tsync < 0) { const char* e = getenv("DBX_P8_TSYNC"); tsync = e ? atoi(e) : 1; }
-            if (!tsync) return launch_conv_p8<T, KS, EPIK, p8::FL_STAGGER>(a, s);
+        // same-box A/B (tools/build_variant.sh -DDBX_P8_AB): DBX_P8_P4=0 / 1 forces four phases of 16 MFMAs / two phases of 32 per K tile
+        if constexpr (FLAGS == p8_default_flags<KS>()) {
+            static int p4 = -2;
+            if (p4 == -2) { const char* e = getenv("DBX_P8_P4"); p4 = e ? atoi(e) : -1; }
+            if (p4 == 0 && (FLAGS & p8::FL_P4)) return launch_conv_p8<T, KS, EPIK, p8::FL_STAGGER | p8::FL_TSYNC>(a, s);
+            if (p4 == 1 && !(FLAGS & p8::FL_P4)) return launch_conv_p8<T, KS, EPIK, p8::FL_STAGGER | p8::FL_TSYNC | p8::FL_P4>(a, s);
         }
 #endif
         constexpr int LDS = p8::LDS_BYTES + (EPIK == 1 ? 32768 : 0);        // + the two groups' 16-KB reduction areas of the fused second convs
@@ -340,6 +376,10 @@ static int launch_conv_p8(const ConvArgs& a, hipStream_t s) {
         t.nkt = KS * KS * (a.cpt / 8);
         t.HW = a.HoWo; t.W = a.Wo;
         t.inv_HW = 1.0f / (float)a.HoWo; t.inv_W = 1.0f / (float)a.Wo;
+        t.stamp = nullptr;
+#ifdef DBX_P8_STAMP
+        t.stamp = p8_next_stamp();
+#endif
         const int grid = t.items < ncu ? t.items : ncu;
         hipLaunchKernelGGL((conv3x3_p8_kernel<T, KS, FLAGS, EPIK>), dim3(grid), dim3(512), LDS, s, a, t);
         DBX_LAUNCH_CHECK();
@@ -357,6 +397,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, c
     static_assert(ES == 2 && (EPIK == 0 || EPIK == 2), "16-bit types; bias / ReLU or gate epilogue");
     constexpr int NTAPS = KS * KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    P8_STAMP_IN(t);
     const p8w::Lanes L = p8w::lanes(smem);
     const int lane = L.lane, wave = L.wave;
     const int pix_bytes = a.x_ld * ES;
@@ -517,6 +558,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, c
             for (int j = 0; j < 2; ++j) vcur[mh][j] = vnxt[mh][j];
     }
     p8w::finish();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    P8_STAMP_OUT(t);
 }
 
 // tiles of 14 .. 16 units of 32 pixels, their number rounded up to whole rounds of CUs
@@ -552,6 +595,10 @@ static int launch_conv_p8w(const ConvArgs& a, hipStream_t s) {
         t.nkt = KS * KS * (a.cpt / 8);
         t.HW = a.HoWo; t.W = a.Wo;
         t.inv_HW = 1.0f / (float)a.HoWo; t.inv_W = 1.0f / (float)a.Wo;
+        t.stamp = nullptr;
+#ifdef DBX_P8_STAMP
+        t.stamp = p8_next_stamp();
+#endif
         const int grid = t.items < ncu ? t.items : ncu;
         hipLaunchKernelGGL((conv3x3_p8w_kernel<T, KS, EPIK>), dim3(grid), dim3(512), p8w::LDS_BYTES, s, a, t);
         DBX_LAUNCH_CHECK();

@@ -15,6 +15,7 @@
 // un-padded 3x3/5x5 refine convs, the Cin=3/5 layers (SMALLC: one 16-byte chunk per tap) and -- with
 // flipped/transposed packed weights -- every dgrad.
 #include "common.hpp"
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 

@@ -38,6 +38,7 @@ constexpr int LDS_BYTES = 131072;
 constexpr int FL_PRIO = 1;        // s_setprio 1 around the MFMA cluster
 constexpr int FL_STAGGER = 2;     // the two wave groups run one barrier apart
 constexpr int FL_TSYNC = 8;       // persistent kernels: the wave groups meet at every tile seam (their epilogues run side by side) and part again behind it
+constexpr int FL_P4 = 64;         // two phases per K tile (clusters of 32 MFMAs): ktiles4 / prologue4 / start4
 constexpr int FL_NODMA = 16;      // probe ablation (wrong results): no LDS-DMA inside the K loop
 constexpr int FL_NOREAD = 32;     // probe ablation (wrong results): no fragment reads inside the K loop
 constexpr int FL_SAFE = 4;        // debugging: every phase drains vmcnt / lgkmcnt in front of its first barrier (separates layout bugs from ordering bugs)
@@ -247,13 +248,18 @@ __device__ __forceinline__ void ktiles(Acc<MF>& acc, const Lanes<MF>& L, int nkt
 // first barrier, so a half-tile may be re-staged one phase after its last read: Y of K tile kt stages B[0], B[1] of kt + 2, X of kt + 1
 // stages A[0], A[1] of kt + 2; the wait in Y (at most the 4 LDS-DMA it has just issued in flight) retires the whole next K tile.
 // Prologue: K tile 0 and B[0], B[1] of K tile 1 (then vmcnt(4)).
-template <typename T, int FLAGS, typename SA, typename SB>
+template <typename T, int FLAGS, int MI1 = 4, typename SA, typename SB>
 __device__ __forceinline__ void ktiles4(Acc<16>& acc, const Lanes<16>& L, int nkt, SA stA, SB stB) {
+    static_assert(MI1 >= 2 && MI1 <= 4, "tile height");
     u32x4 af[8], bf[2][4];
     auto rdA = [&](auto D_, auto H_) {
-        constexpr int base = (decltype(D_)::value * 2 + decltype(H_)::value) * 16384;
-        lds_read<base + 0 * 2048>(af[0], L.ra[0]); lds_read<base + 1 * 2048>(af[1], L.ra[0]); lds_read<base + 2 * 2048>(af[2], L.ra[0]); lds_read<base + 3 * 2048>(af[3], L.ra[0]);
-        lds_read<base + 0 * 2048>(af[4], L.ra[1]); lds_read<base + 1 * 2048>(af[5], L.ra[1]); lds_read<base + 2 * 2048>(af[6], L.ra[1]); lds_read<base + 3 * 2048>(af[7], L.ra[1]);
+        constexpr int mh = decltype(H_)::value, base = (decltype(D_)::value * 2 + mh) * 16384, NI = mh == 0 ? 4 : MI1;
+        lds_read<base + 0 * 2048>(af[0], L.ra[0]); lds_read<base + 1 * 2048>(af[1], L.ra[0]);
+        if constexpr (NI > 2) lds_read<base + 2 * 2048>(af[2], L.ra[0]);
+        if constexpr (NI > 3) lds_read<base + 3 * 2048>(af[3], L.ra[0]);
+        lds_read<base + 0 * 2048>(af[4], L.ra[1]); lds_read<base + 1 * 2048>(af[5], L.ra[1]);
+        if constexpr (NI > 2) lds_read<base + 2 * 2048>(af[6], L.ra[1]);
+        if constexpr (NI > 3) lds_read<base + 3 * 2048>(af[7], L.ra[1]);
     };
     auto rdB = [&](auto D_, auto H_) {
         constexpr int nh = decltype(H_)::value, base = (decltype(D_)::value * 2 + nh) * 16384;
@@ -261,11 +267,11 @@ __device__ __forceinline__ void ktiles4(Acc<16>& acc, const Lanes<16>& L, int nk
         lds_read<base>(bf[nh][2], L.rb[1]); lds_read<base + 2048>(bf[nh][3], L.rb[1]);
     };
     auto cluster = [&](auto MH_, auto NH_) {
-        constexpr int mh = decltype(MH_)::value, nh = decltype(NH_)::value;
+        constexpr int mh = decltype(MH_)::value, nh = decltype(NH_)::value, NI = mh == 0 ? 4 : MI1;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < NI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) Mma16<T>::run(bf[nh][kk * 2 + ni], af[kk * 4 + mi], acc.v[mh][nh][mi][ni]);
     };
@@ -301,7 +307,7 @@ template <int FLAGS>
 __device__ __forceinline__ void start4(const Lanes<16>& L) {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     barrier();
-    if ((FLAGS & FL_STAGGER) && L.wr == 1) barrier();
+    if ((FLAGS & FL_STAGGER) && !(FLAGS & FL_TSYNC) && L.wr == 1) barrier();
 }
 }  // namespace p8
 

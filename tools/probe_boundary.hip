@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <vector>
 #include <algorithm>
+#include <chrono>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 struct Stamp { unsigned long long t0, t1; };
@@ -72,6 +73,34 @@ int main() {
         std::sort(gap.begin(), gap.end()); std::sort(gap2.begin(), gap2.end());
         printf("%-58s %8.2f us %8.2f us %8.2f us %9.2f us   (back to the small kernel: %.2f us)\n", c.name, gap[gap.size() / 2], gap.front(), gap.back(),
                ms * 1e3 / REP, gap2[gap2.size() / 2]);
+    }
+    // ---- the real step's pattern: the host enqueues kernels ONE CALL AT A TIME with ~30 us of host work between the calls (ctypes + Python), the
+    // GPU is the bottleneck (each kernel runs 100 us), so the queue is never empty.  profiles/r05_f16_timeline.txt (rocprofv3) shows ~10 us in
+    // front of the first kernel of every host call and 0 between two kernels one call enqueues back to back.  Stamps = truth.
+    {
+        const int REP2 = 60;
+        std::vector<Stamp> h(3 * REP2);
+        for (auto& s : h) { s.t0 = ~0ull; s.t1 = 0; }
+        Stamp* st3; CK(hipMalloc(&st3, sizeof(Stamp) * 3 * REP2));
+        CK(hipMemcpy(st3, h.data(), sizeof(Stamp) * 3 * REP2, hipMemcpyHostToDevice));
+        for (int i = 0; i < REP2; ++i) {
+            // one "host call": a big-LDS kernel and a small follow-up kernel back to back, then host work
+            hipLaunchKernelGGL(work_kernel, dim3(256), dim3(512), 128 << 10, 0, st3, 3 * i, 10000, (float*)nullptr, (size_t)0);
+            hipLaunchKernelGGL(work_kernel, dim3(256), dim3(256), 0, 0, st3, 3 * i + 1, 2000, (float*)nullptr, (size_t)0);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 30.0) {}
+        }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h.data(), st3, sizeof(Stamp) * 3 * REP2, hipMemcpyDeviceToHost));
+        std::vector<double> g_first, g_second;
+        for (int i = 5; i < REP2; ++i) {
+            g_first.push_back((double)(long long)(h[3 * i].t0 - h[3 * (i - 1) + 1].t1) * 0.01);      // previous call's last kernel -> this call's first
+            g_second.push_back((double)(long long)(h[3 * i + 1].t0 - h[3 * i].t1) * 0.01);           // inside one call
+        }
+        std::sort(g_first.begin(), g_first.end()); std::sort(g_second.begin(), g_second.end());
+        printf("\nhost calls 30 us apart, GPU-bound queue (100 us + 20 us kernels per call):\n");
+        printf("  in front of the first kernel of a call (256 x 512 thr, 128 KB LDS): median %.2f us  min %.2f  max %.2f\n", g_first[g_first.size() / 2], g_first.front(), g_first.back());
+        printf("  between the two kernels of one call:                               median %.2f us  min %.2f  max %.2f\n", g_second[g_second.size() / 2], g_second.front(), g_second.back());
     }
     return 0;
 }

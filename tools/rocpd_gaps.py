@@ -15,6 +15,7 @@ for i in range(1, len(rows)):
         order.append(key)
     groups.setdefault(key, []).append((rows[i][0] - rows[i - 1][1]) / 1e3)
 print('columns:', want)
+# (the last section of the probe: pairs of a (512, 131072) and a (256, 65536) launch per host call, 30 us of host work between calls)
 for k in order:
     g = groups[k]
     print('%-40s launches %5d  gap median %7.2f us  min %7.2f  max %7.2f' % (str(k), len(g), statistics.median(g), min(g), max(g)))
