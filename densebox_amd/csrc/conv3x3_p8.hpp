@@ -124,6 +124,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
         if (ox < 0) { --oy; ox += t.W; }
         if (ox >= t.W) { ++oy; ox -= t.W; }
     };
+    // the pixel 16 further on (the next fragment row of a wave): at most one row wrap when W >= 16, else divide again
+    auto advance16 = [&](int p, int& n, int& oy, int& ox) {
+        if (t.W >= 16) {
+            ox += 16;
+            if (ox >= t.W) { ox -= t.W; if (++oy * t.W >= t.HW) { oy = 0; ++n; } }
+        } else split(p, n, oy, ox);
+    };
     // tile row (half mh, row r of the half's 128 LDS rows) -> pixel index offset from p0; 7-unit tiles use rows 0..47 of each wave's 64 of half 1
     auto row_index = [&](int nf, int mh, int r) { return mh == 0 ? r : (nf == 8 ? 128 + r : 128 + (r >> 6) * 48 + ((r & 63) < 48 ? (r & 63) : 0)); };
     // ---- LDS-DMA source offsets of a tile's pixel rows: this lane loads LDS row 64 j + 8 wave + (lane >> 3) of each half-tile
@@ -217,15 +224,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                 }
                 char* const red = smem + p8::LDS_BYTES + L.wr * 16384;
 #pragma unroll
-                for (int mh = 0; mh < 2; ++mh)
+                for (int mh = 0; mh < 2; ++mh) {
+                    int n, oy, ox;                                          // pixel of this lane's fragment row mi: divided out once per half, then stepped
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) {
                         if (mh == 1 && mi >= MI1) continue;
                         const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + l15);
                         const bool ok = p < pend;
                         const int pp = ok ? p : cur.p0;
-                        int n, oy, ox;
-                        split(pp, n, oy, ox);
+                        if (mi == 0) split(p, n, oy, ox); else advance16(p, n, oy, ox);
                         const size_t yo = (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (size_t)a.y_ld;
                         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -248,6 +255,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                         // rows 4 g .. 4 g + 3 of the second convs' outputs for pixel l15: only g < 2 (k <= 8) carries anything
                         if (a.w2f && g4 < 2) *(f32x4*)(red + ((L.wc * 8 + mh * 4 + mi) * 32 + (lane & 31)) * 16) = acc2;
                     }
+                }
                 if (a.w2f) {
                     // the group's four waves, summed in wave order; wave wc finishes fragments 2 wc and 2 wc + 1.  The barrier is the
                     // whole workgroup's (every wave runs the same barrier sequence one phase apart: the stagger is unchanged)
@@ -280,21 +288,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
             // store is issued behind it, and the epilogue has nothing else to hide a memory latency under (the operand fragments' 64
             // registers are free here)
 #pragma unroll
-            for (int mh = 0; mh < 2; ++mh)
+            for (int mh = 0; mh < 2; ++mh) {
+                int n, oy, ox;                                              // divided out once per half, then stepped 16 pixels per fragment row
+                size_t go0 = 0;
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     if (mh == 1 && mi >= MI1) continue;
                     const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + (lane & 15));
                     ok[mh][mi] = p < pend;
-                    int n, oy, ox;
-                    split(ok[mh][mi] ? p : cur.p0, n, oy, ox);
+                    if (mi == 0) split(p < a.M ? p : a.M - 1, n, oy, ox); else advance16(p, n, oy, ox);
                     yo[mh][mi] = (unsigned)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (unsigned)a.y_ld;
                     if constexpr (EPIK == 2) {
-                        const size_t go = (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld;
+                        size_t go = (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld;
+                        if (mi == 0) go0 = go;
+                        if (!ok[mh][mi]) go = go0;                          // rows past the tile's end: any address that exists
 #pragma unroll
                         for (int nh = 0; nh < 2; ++nh) gt[mh][mi][nh] = *(const u32x4*)(gbase + go + nh * 128 + nc);
                     }
                 }
+            }
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
