@@ -131,7 +131,10 @@ class Plan:
             # dbx_heads1_dgrad_gen / dbx_head2_backward_up without a d_hid: round 4; DBX_HEADS_GEN=0 keeps it in memory).  A backward that
             # cannot use them (an injected dropout mask, a side stream) gets the buffer on demand (Engine._d_hid).
             L = _lib.lib()
-            self.heads_gen = bool(heads_gen and lin_bwd and
+            # (the generating kernels' own limits, checked by DBX_REQUIRE at backward time: < 2^24 pixels, d_out below 2 GiB, k <= 8 per head --
+            #  a plan outside them keeps the hidden gradient in memory instead of failing in backward_raw)
+            gen_fits = n * h4 * w4 < (1 << 24) and n * h4 * w4 * self.crf * nh * es < (1 << 31) and self.crf <= 8
+            self.heads_gen = bool(heads_gen and lin_bwd and gen_fits and
                                   L.dbx_head2_backward_up_fused(dtype_id, C.byref(B['hid'].view()), C.byref(B['d_g44'].view())) and
                                   L.dbx_heads1_wgrad_gen_ok(dtype_id, C.byref(B['fusion'].view(512, 256)), nh))
             if not self.heads_gen:
@@ -494,6 +497,8 @@ class Engine:
         pidx = {p.data_ptr(): i for i, p in enumerate(live)}
         skey = (tkey, tuple(pidx))
         st = self._sgd_tables.get(skey)
+        if st is False:
+            return False                                  # (this configuration does not fit the fused kernel: decided once, not per step)
         if st is None:
             import numpy as np
             by_src, order = {}, []
@@ -509,6 +514,7 @@ class Engine:
                 if src not in pidx:
                     continue                              # no gradient: unchanged, its packed copies stay valid
                 if len(js) > 4 or len({(j[2], j[3], j[4]) for j in js}) != 1:
+                    self._sgd_tables = {skey: False}
                     return False
                 co, ci, taps = js[0][2], js[0][3], js[0][4]
                 tiled = es == 2 and taps <= 25 and all(
@@ -737,7 +743,8 @@ class Engine:
                 prof.append({'kernel': self.conv_plan(dt, a11v, a12v, 3, 3, 1, 64, 64, RELU)[1],
                              'flops': 2.0 * a12v.n * a12v.h * a12v.w * 9 * 64 * 64, 'start': ev0, 'end': ev1})
         else:
-            assert not P.a12_alias, 'conv1_2 + pool1 not fusable on a plan without a full-resolution conv1_2 map'
+            if P.a12_alias:                                  # (the plan's alias rule and the library's fusability rule must agree: never an assert)
+                raise RuntimeError('conv1_2 + pool1 not fusable on a plan without a full-resolution conv1_2 map')
             conv3('conv1_2_1', 'a11', 'a12', 64, 64)
             pool(a12v, p1v, 'a12')
         conv3('conv2_1_1', 'p1', 'a21', 64, 128)
