@@ -225,14 +225,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                 char* const red = smem + p8::LDS_BYTES + L.wr * 16384;
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh) {
-                    int n, oy, ox;                                          // pixel of this lane's fragment row mi: divided out once per half, then stepped
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) {
                         if (mh == 1 && mi >= MI1) continue;
                         const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + l15);
                         const bool ok = p < pend;
                         const int pp = ok ? p : cur.p0;
-                        if (mi == 0) split(p, n, oy, ox); else advance16(p, n, oy, ox);
+                        int n, oy, ox;                                      // (divided out per row: carrying the coordinates across the rows spilled 10 registers here)
+                        split(pp, n, oy, ox);
                         const size_t yo = (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (size_t)a.y_ld;
                         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
