@@ -26,12 +26,54 @@ template <int B> __device__ __forceinline__ float p8_keep(float v, unsigned h) {
     return __builtin_bit_cast(float, __builtin_bit_cast(int, v) & m);
 }
 
+// ---- 2x2 max-pool fused into an epilogue (EPIK 3; DenseBox.py:191, :204: MaxPool2d(2, 2) behind conv2_2 / conv3_4).  The kernels enumerate
+// their pixels WINDOW-MAJOR for it (p = 4 w + j: w = compact index of the pooled pixel, j = 2 dy + dx -- a lane's LDS-DMA source address is
+// arbitrary, so the order costs nothing), which puts the four pixels of a window into the four lanes of a quad with the same eight
+// channels (one 16-byte chunk each, rounded, >= +0 after the ReLU: the 16-bit patterns order like the numbers).  A 4 x 4 transpose over
+// the quad (two cndmask / DPP / cndmask rounds) leaves lane j with the window's four values of channels 2 j, 2 j + 1; the window logic of
+// conv3x3_c64_kernel's pooled epilogue runs ONCE per lane on packed unsigned halves (first maximum in (0,0), (0,1), (1,0), (1,1) order,
+// as ATen; nibble = position | (max > 0) << 2: bitwise what dbx_maxpool2x2_idx takes from the stored map), and the quad stores 16 bytes
+// of the pooled map and 4 bytes of nibbles.  ~45 VALU instructions per chunk.
+__device__ __forceinline__ void p8_pool_chunk(const u32x4& chunk, int lane, bool ok, char* ppix, unsigned char* ipix) {
+    const int j = lane & 3;
+    unsigned o[4] = {chunk.x & 0x7fff7fffu, chunk.y & 0x7fff7fffu, chunk.z & 0x7fff7fffu, chunk.w & 0x7fff7fffu};     // (-0 -> +0: keeps the unsigned order)
+#pragma unroll
+    for (int e = 0; e < 4; e += 2) {                                    // lanes j ^ 1 exchange dwords (e, e + 1)
+        const unsigned send = (j & 1) ? o[e] : o[e + 1];
+        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0xB1, 0xF, 0xF, true);
+        if (j & 1) o[e] = recv; else o[e + 1] = recv;
+    }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                                       // lanes j ^ 2 exchange dwords (e, e + 2)
+        const unsigned send = (j & 2) ? o[e] : o[e + 2];
+        const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, 0x4E, 0xF, 0xF, true);
+        if (j & 2) o[e] = recv; else o[e + 2] = recv;
+    }
+    auto pk_max = [](unsigned x, unsigned y) { unsigned d; asm("v_pk_max_u16 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    auto pk_min = [](unsigned x, unsigned y) { unsigned d; asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    auto pk_sub = [](unsigned x, unsigned y) { unsigned d; asm("v_pk_sub_u16 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y)); return d; };
+    auto pk_mad = [](unsigned x, unsigned y, unsigned z) { unsigned d; asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z)); return d; };
+    const unsigned one = 0x00010001u, two = 0x00020002u, four = 0x00040004u;
+    const unsigned A = o[0], B = o[1], Cc = o[2], D = o[3];             // window positions (0,0), (0,1), (1,0), (1,1) of channels 2 j (low half), 2 j + 1
+    const unsigned t0 = pk_max(A, B), t1 = pk_max(Cc, D), m = pk_max(t0, t1);
+    const unsigned h0 = pk_min(t0 ^ A, one);                            // 1: the second column is strictly larger (row 0)
+    const unsigned h1 = pk_min(t1 ^ Cc, one);                           //    ... (row 1)
+    const unsigned r = pk_min(m ^ t0, one);                             // 1: row 1 is strictly larger
+    const unsigned pos = pk_min(m, one);
+    const unsigned b0 = pk_mad(r, pk_sub(h1, h0), h0);                  // r ? h1 : h0  (mod 2^16)
+    const unsigned nib = pk_mad(pos, four, pk_mad(r, two, b0));
+    if (ok) {
+        *(unsigned*)(ppix + 4 * j) = m;                                  // channels 2 j, 2 j + 1 of the pooled pixel
+        if (ipix) ipix[j] = (unsigned char)((nib & 0xfu) | ((nib >> 12) & 0xf0u));
+    }
+}
+
 struct P8Args {
     int mt;              // pixel tiles
     int base, extra;     // tile t covers base + (t < extra) units of 32 pixels, starting at unit t base + min(t, extra)
     int items;           // mt * ntile_n
     int nkt;             // K tiles: taps * cin / 64 (even)
-    int HW, W;           // output pixels per image / per row
+    int HW, W;           // output pixels per image / per row (EPIK 3: POOLED pixels per image / per row: the enumeration is window-major)
     float inv_HW, inv_W;
     unsigned long long* stamp;   // lab builds (-DDBX_P8_STAMP): {first workgroup in, last workgroup out} of this launch in s_memrealtime ticks (10 ns), else null
 };
@@ -114,7 +156,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
         return r;
     };
     // pixel index -> (image, row, column): float estimate + one correction step (exact for p < 2^24)
-    auto split = [&](int p, int& n, int& oy, int& ox) {
+    auto split0 = [&](int p, int& n, int& oy, int& ox) {
         n = (int)(((float)p + 0.5f) * t.inv_HW);
         int r = p - n * t.HW;
         if (r < 0) { --n; r += t.HW; }
@@ -123,6 +165,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
         ox = r - oy * t.W;
         if (ox < 0) { --oy; ox += t.W; }
         if (ox >= t.W) { ++oy; ox -= t.W; }
+    };
+    // EPIK 3 (fused pooling): window-major enumeration p = 4 w + (2 dy + dx), w = compact index of the pooled pixel (t.HW / t.W are the pooled dims)
+    auto split = [&](int p, int& n, int& oy, int& ox) {
+        if constexpr (EPIK == 3) { split0(p >> 2, n, oy, ox); oy = 2 * oy + ((p >> 1) & 1); ox = 2 * ox + (p & 1); }
+        else split0(p, n, oy, ox);
     };
     // the pixel 16 further on (the next fragment row of a wave): at most one row wrap when W >= 16, else divide again
     auto advance16 = [&](int p, int& n, int& oy, int& ox) {
@@ -276,6 +323,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                 }
                 return;
             }
+            if constexpr (EPIK == 3) {
+                // ---- bias + ReLU, the full map unless the caller wants the pooled one only, and the 2x2 max-pool of the tile (p8_pool_chunk)
+                const int pend = cur.p0 + cur.nf * 32 < a.M ? cur.p0 + cur.nf * 32 : a.M;
+                T* const ybase = (T*)a.y + cur.n0;
+                const int nc = L.wc * 32 + pair_cout_off(g4, 0);
+                const bool full = !(a.epi2 & EPI2_POOL_ONLY);
+#pragma unroll
+                for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        if (mh == 1 && mi >= MI1) continue;
+                        const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + (lane & 15));
+                        const bool ok = p < pend;
+                        const int pp = ok ? p : cur.p0;
+                        int n, py, px;
+                        split0(pp >> 2, n, py, px);
+                        const int oy = 2 * py + ((pp >> 1) & 1), ox = 2 * px + (pp & 1);
+                        // (element offsets in 32 bits: both maps are < 4 G elements, checked by the host; 24-bit multiplies run at full rate)
+                        const unsigned yo = (__umul24(__umul24(n, a.y_hp) + oy + a.y_pad, a.y_wp) + ox + a.y_pad) * (unsigned)a.y_ld;
+                        const unsigned po = (__umul24(__umul24(n, a.y2_hp) + py + a.y2_pad, a.y2_wp) + px + a.y2_pad) * (unsigned)a.y2_ld;
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh) {
+                            f32x4 v0 = acc.v[mh][nh][mi][0] + bias[nh][0], v1 = acc.v[mh][nh][mi][1] + bias[nh][1];
+                            v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                            v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+                            const u32x4 o = pair_exchange<T>(v0, v1);
+                            const int ch = cur.n0 + nh * 128 + nc;           // first of this lane's eight couts
+                            if (ok && full) *(u32x4*)(ybase + yo + nh * 128 + nc) = o;
+                            p8_pool_chunk(o, lane, ok, (char*)((T*)a.y2 + po + ch),
+                                          a.pool_idx ? a.pool_idx + ((unsigned)(pp >> 2) * (unsigned)(a.cout_valid >> 1) + (unsigned)(ch >> 1)) : nullptr);
+                        }
+                    }
+                return;
+            }
             // ---- epilogue (compiler-scheduled; no LDS).  Row m of half mh -> output pixel; chunk = eight consecutive couts of it
             const int pend = cur.p0 + cur.nf * 32 < a.M ? cur.p0 + cur.nf * 32 : a.M;
             T* const ybase = (T*)a.y + cur.n0;
@@ -387,7 +468,8 @@ static int launch_conv_p8(const ConvArgs& a, hipStream_t s) {
         DBX_REQUIRE(p8_schedule(a.M, a.ntile_n, ncu, t), "conv p8: no 7/8-unit tile schedule for %d pixels", a.M);
         t.nkt = KS * KS * (a.cpt / 8);
         t.HW = a.HoWo; t.W = a.Wo;
-        t.inv_HW = 1.0f / (float)a.HoWo; t.inv_W = 1.0f / (float)a.Wo;
+        if (EPIK == 3) { t.HW = a.HoWo / 4; t.W = a.Wo / 2; }          // window-major enumeration: the pooled map's dims
+        t.inv_HW = 1.0f / (float)t.HW; t.inv_W = 1.0f / (float)t.W;
         t.stamp = nullptr;
 #ifdef DBX_P8_STAMP
         t.stamp = p8_next_stamp();
@@ -406,7 +488,7 @@ static int launch_conv_p8(const ConvArgs& a, hipStream_t s) {
 template <typename T, int KS, int EPIK = 0>
 __global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, const P8Args t) {
     constexpr int ES = sizeof(T);
-    static_assert(ES == 2 && (EPIK == 0 || EPIK == 2), "16-bit types; bias / ReLU or gate epilogue");
+    static_assert(ES == 2 && (EPIK == 0 || EPIK == 2 || EPIK == 3), "16-bit types; bias / ReLU, gate, or bias + ReLU + pooling epilogue");
     constexpr int NTAPS = KS * KS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     P8_STAMP_IN(t);
@@ -429,7 +511,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, c
         r.n0 = tn * 128;
         return r;
     };
-    auto split = [&](int p, int& n, int& oy, int& ox) {
+    auto split0 = [&](int p, int& n, int& oy, int& ox) {
         n = (int)(((float)p + 0.5f) * t.inv_HW);
         int r = p - n * t.HW;
         if (r < 0) { --n; r += t.HW; }
@@ -438,6 +520,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, c
         ox = r - oy * t.W;
         if (ox < 0) { --oy; ox += t.W; }
         if (ox >= t.W) { ++oy; ox -= t.W; }
+    };
+    auto split = [&](int p, int& n, int& oy, int& ox) {              // EPIK 3: window-major enumeration (see p8_pool_chunk)
+        if constexpr (EPIK == 3) { split0(p >> 2, n, oy, ox); oy = 2 * oy + ((p >> 1) & 1); ox = 2 * ox + (p & 1); }
+        else split0(p, n, oy, ox);
     };
     // tile row (half mh, LDS row r of its 128) -> pixel offset from p0: a half with three fragments per wave uses rows 0..47 of each wave's 64
     auto row_index = [&](int nf, int mh, int r) {
@@ -518,6 +604,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, c
             T* const ybase = (T*)a.y + cur.n0;
             const T* const gbase = (const T*)a.gate + cur.n0;
             const int nc = L.wc * 32 + pair_cout_off(g4, 0);
+            if constexpr (EPIK == 3) {
+                // ---- bias + ReLU, the full map unless the caller wants the pooled one only, and the 2x2 max-pool of the tile (p8_pool_chunk)
+                const bool full = !(a.epi2 & EPI2_POOL_ONLY);
+                const int ch = cur.n0 + nc;
+#pragma unroll
+                for (int mh = 0; mh < 4; ++mh)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi) {
+                        if ((mh == 2 && mi >= MI2) || (mh == 3 && mi >= MI3)) continue;
+                        const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + (lane & 15));
+                        const bool ok = p < pend;
+                        const int pp = ok ? p : cur.p0;
+                        int n, py, px;
+                        split0(pp >> 2, n, py, px);
+                        const int oy = 2 * py + ((pp >> 1) & 1), ox = 2 * px + (pp & 1);
+                        // (element offsets in 32 bits: both maps are < 4 G elements, checked by the host; 24-bit multiplies run at full rate)
+                        const unsigned yo = (__umul24(__umul24(n, a.y_hp) + oy + a.y_pad, a.y_wp) + ox + a.y_pad) * (unsigned)a.y_ld;
+                        const unsigned po = (__umul24(__umul24(n, a.y2_hp) + py + a.y2_pad, a.y2_wp) + px + a.y2_pad) * (unsigned)a.y2_ld;
+                        f32x4 v0 = acc.v[mh][mi][0] + bias[0], v1 = acc.v[mh][mi][1] + bias[1];
+                        v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                        v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+                        const u32x4 o = pair_exchange<T>(v0, v1);
+                        if (ok && full) *(u32x4*)(ybase + yo + nc) = o;
+                        p8_pool_chunk(o, lane, ok, (char*)((T*)a.y2 + po + ch),
+                                      a.pool_idx ? a.pool_idx + ((unsigned)(pp >> 2) * (unsigned)(a.cout_valid >> 1) + (unsigned)(ch >> 1)) : nullptr);
+                    }
+                return;
+            }
             // two batches of eight pixel rows: addresses + the batch's gate chunks first, then its stores
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {
@@ -606,7 +720,8 @@ static int launch_conv_p8w(const ConvArgs& a, hipStream_t s) {
         DBX_REQUIRE(p8w_schedule(a.M, a.ntile_n, ncu, t), "conv p8w: no 14..16-unit tile schedule for %d pixels", a.M);
         t.nkt = KS * KS * (a.cpt / 8);
         t.HW = a.HoWo; t.W = a.Wo;
-        t.inv_HW = 1.0f / (float)a.HoWo; t.inv_W = 1.0f / (float)a.Wo;
+        if (EPIK == 3) { t.HW = a.HoWo / 4; t.W = a.Wo / 2; }          // window-major enumeration: the pooled map's dims
+        t.inv_HW = 1.0f / (float)t.HW; t.inv_W = 1.0f / (float)t.W;
         t.stamp = nullptr;
 #ifdef DBX_P8_STAMP
         t.stamp = p8_next_stamp();

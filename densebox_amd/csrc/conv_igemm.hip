@@ -1526,8 +1526,19 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
     a.pool_idx = (unsigned char*)pool_idx;
     a.w2f = (const char*)w2_frag; a.part = part;
     a.rowskip = 0;
-    if (y2 && (epi2 & EPI2_POOL)) {
-        // pooled second destination: the 64 -> 64 halo-tile kernel only (dbx_conv_pool_fusable)
+    bool pool_p8 = false;       // pooled second destination on the 8-phase kernels (round 5: conv2_2 -> pool2, conv3_4 -> pool3; EPIK 3)
+    if (y2 && (epi2 & EPI2_POOL) && !c64_pool_ok<T>(d, x, y)) {
+        DBX_REQUIRE(sizeof(T) == 2 && d->kh == 3 && d->kw == 3 && d->cpad == 1 && x->pad == 1 && (d->epilogue & DBX_EPI_RELU) &&
+                    !(d->epilogue & ~(DBX_EPI_BIAS | DBX_EPI_RELU)) && y->h % 2 == 0 && y->w % 2 == 0 && x->h == y->h && x->w == y->w,
+                    "conv pool: needs a 16-bit 3x3/pad 1 layer on congruent frames with even H, W and a (bias +) ReLU epilogue");
+        DBX_REQUIRE(y2->n == y->n && y2->h == y->h / 2 && y2->w == y->w / 2 && y2->c == y->c && ((y2->c_off * ES) % 16) == 0 && (y2->ld * ES) % 16 == 0 &&
+                    (int64_t)y2->n * (y2->h + 2 * y2->pad) * (y2->w + 2 * y2->pad) * y2->ld < ((int64_t)1 << 32), "conv pool: pooled view must be N x H/2 x W/2 x C, 16-byte aligned");
+        a.y2 = (char*)y2->ptr + (size_t)y2->c_off * ES;
+        a.y2_hp = y2->h + 2 * y2->pad; a.y2_wp = y2->w + 2 * y2->pad; a.y2_ld = y2->ld; a.y2_pad = y2->pad;
+        a.epi2 = epi2;
+        pool_p8 = true;
+    } else if (y2 && (epi2 & EPI2_POOL)) {
+        // pooled second destination of the 64 -> 64 halo-tile kernel
         DBX_REQUIRE(c64_pool_ok<T>(d, x, y), "conv pool: needs a 16-bit 3x3/pad 1 64 -> 64 layer on congruent frames with even H, W and a bias/ReLU epilogue");
         DBX_REQUIRE(y2->n == y->n && y2->h == y->h / 2 && y2->w == y->w / 2 && y2->c == 64 && ((y2->c_off * ES) % 16) == 0 && (y2->ld * ES) % 16 == 0 &&
                     ((y->c_off * ES) % 16) == 0 && (y->ld * ES) % 16 == 0, "conv pool: pooled view must be N x H/2 x W/2 x 64, 16-byte aligned");
@@ -1568,7 +1579,7 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         const int taps = d->kh * d->kw;
         // the heads' forward GEMM: bias + hash dropout (+ the second 1x1 convs on the tile when the caller hands over their weights)
         const bool heads = k1 && (d->epilogue & ~DBX_CONV_WFRAG) == (DBX_EPI_BIAS | DBX_EPI_DROPHASH);
-        bool p8_ok = p8_level != 0 && !smallc && sizeof(T) == 2 && (k3 || k1) && !(d->epilogue & DBX_CONV_WFRAG) && !y2 && !pool_idx && (heads || !w2_frag) &&
+        bool p8_ok = p8_level != 0 && !smallc && sizeof(T) == 2 && (k3 || k1) && !(d->epilogue & DBX_CONV_WFRAG) && (!y2 || (pool_p8 && k3)) && (!pool_idx || pool_p8) && (heads || !w2_frag) &&
                      (kk == 0 || kk == DBX_EPI_RELU || (kk == DBX_EPI_GATE && !(d->epilogue & DBX_EPI_BIAS)) || heads) && d->cin_pad % 64 == 0 && (taps * (d->cin_pad / 64)) % 2 == 0 &&
                      taps * (d->cin_pad / 64) >= 4 && taps * (d->cin_pad / 64) < 7000 && d->cout_pad % 256 == 0 && y->c == d->cout_pad &&
                      (y->c_off * ES) % 16 == 0 && (y->ld * ES) % 16 == 0 && a.M < (1 << 24) &&
@@ -1596,13 +1607,14 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
                 return DBX_OK;
             }
             if (heads) return launch_conv_p8<T, 1, 1>(a, s);
+            if (pool_p8) return launch_conv_p8<T, 3, 3>(a, s);
             if (kk == DBX_EPI_GATE) return k3 ? launch_conv_p8<T, 3, 2>(a, s) : launch_conv_p8<T, 1, 2>(a, s);
             return k3 ? launch_conv_p8<T, 3>(a, s) : launch_conv_p8<T, 1>(a, s);
         }
         // 128-cout layers (conv2_2 forward / data gradient, conv3_1's data gradient): 512-pixel x 128-cout tiles on the p8w core (DBX_P8W=0: off)
         static int p8w_on = -1;
         if (p8w_on < 0) { const char* e = getenv("DBX_P8W"); p8w_on = e ? atoi(e) : 1; }
-        bool p8w_ok = p8_level != 0 && p8w_on != 0 && !smallc && sizeof(T) == 2 && k3 && !(d->epilogue & DBX_CONV_WFRAG) && !y2 && !pool_idx && !w2_frag &&
+        bool p8w_ok = p8_level != 0 && p8w_on != 0 && !smallc && sizeof(T) == 2 && k3 && !(d->epilogue & DBX_CONV_WFRAG) && (!y2 || pool_p8) && (!pool_idx || pool_p8) && !w2_frag &&
                       (kk == 0 || kk == DBX_EPI_RELU || (kk == DBX_EPI_GATE && !(d->epilogue & DBX_EPI_BIAS))) && d->cin_pad % 128 == 0 &&
                       9 * (d->cin_pad / 64) < 7000 && d->cout_pad % 128 == 0 && d->cout_pad % 256 != 0 && y->c == d->cout_pad &&
                       (y->c_off * ES) % 16 == 0 && (y->ld * ES) % 16 == 0 && a.M < (1 << 24) &&
@@ -1622,8 +1634,10 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
                 snprintf(plan->name, sizeof plan->name, "conv3x3_p8w_kernel<%s,3>", tname);
                 return DBX_OK;
             }
+            if (pool_p8) return launch_conv_p8w<T, 3, 3>(a, s);
             return kk == DBX_EPI_GATE ? launch_conv_p8w<T, 3, 2>(a, s) : launch_conv_p8w<T, 3>(a, s);
         }
+        DBX_REQUIRE(!pool_p8, "conv pool: the problem does not qualify for a pooling epilogue (ask dbx_conv_pool_fusable)");
         DBX_REQUIRE(!(w2_frag && !(d->epilogue & DBX_CONV_WFRAG)), "heads forward fused: plain-layout weights, but the problem does not qualify for the 8-phase kernel (ask dbx_heads_forward_fusable)");
     }
     // Wide 16-bit layers with enough tiles to fill the chip: register-streamed weights (conv3x3_ws.hpp) -- the 3x3 / pad 1
@@ -1977,7 +1991,19 @@ extern "C" int dbx_conv_dgrad_wgrad1(const dbx_conv_desc* d, const dbx_view* dz,
 }
 
 template <typename T>
-static int conv_pool_ok_t(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y) { return c64_pool_ok<T>(d, x, y) ? 1 : 0; }
+static int conv_pool_ok_t(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y) {
+    if (c64_pool_ok<T>(d, x, y)) return 1;
+    // the 8-phase kernels' pooling epilogue: whatever the one selection path gives a pooled call (asked in plan mode with a stand-in pooled view)
+    if (sizeof(T) != 2 || y->h % 2 || y->w % 2 || y->h < 2 || y->w < 2 || (y->c * (int)sizeof(T)) % 16) return 0;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("DBX_P8_POOL"); on = e ? atoi(e) : 1; }
+    if (!on) return 0;
+    dbx_view yp = *y;
+    yp.h = y->h / 2; yp.w = y->w / 2; yp.pad = 1; yp.ld = y->c; yp.c_off = 0;
+    dbx_conv_plan_t pl;
+    const int rc = conv_forward_t<T>(d, x, nullptr, nullptr, y, nullptr, nullptr, 0, nullptr, &yp, nullptr, 0, EPI2_POOL, &pl);
+    return rc == DBX_OK && pl.kernel == DBX_K_P8 ? 1 : 0;
+}
 extern "C" int dbx_conv_pool_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y) {
     if (!d || !x || !y) return 0;
     switch (d->dtype) {

@@ -747,14 +747,34 @@ class Engine:
                 raise RuntimeError('conv1_2 + pool1 not fusable on a plan without a full-resolution conv1_2 map')
             conv3('conv1_2_1', 'a11', 'a12', 64, 64)
             pool(a12v, p1v, 'a12')
+        def conv3_pool(stem, src, yv, pv, c, key, keep_full):
+            """3x3 conv + bias + ReLU with the following MaxPool2d(2, 2) in the 8-phase kernels' epilogue when the library takes it (16-bit,
+            even H, W): the pooling kernel's re-read of the map goes away, and so does the map itself when nothing else reads it (a22:
+            its other reader was pool2's backward, which reads the nibbles)."""
+            d = ConvDesc(dt, 3, 3, 1, c, c, RELU, 0)
+            xv = B[src].view()
+            if not L.dbx_conv_pool_fusable(C.byref(d), C.byref(xv), C.byref(yv)):
+                conv3(stem, src, None, c, c, dst_view=yv)
+                pool(yv, pv, key)
+                return
+            prof = self.profile
+            if prof is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            check(L.dbx_conv_forward_pool_idx(C.byref(d), C.byref(xv), ptr(self._w_fwd(dt, stem, c, c, frag=False)), ptr(self._bias([stem], c)),
+                                              C.byref(yv), C.byref(pv), 1 if keep_full else 0, ptr(PI[key]) if PI else None, s))
+            if prof is not None:
+                ev1.record()
+                prof.append({'kernel': self.conv_plan(dt, xv, yv, 3, 3, 1, c, c, RELU)[1],
+                             'flops': 2.0 * yv.n * yv.h * yv.w * 9 * c * c, 'start': ev0, 'end': ev1})
+
         conv3('conv2_1_1', 'p1', 'a21', 64, 128)
-        conv3('conv2_2_1', 'a21', 'a22', 128, 128)
-        pool(B['a22'].view(), B['p2'].view(), 'a22')
+        # the full conv2_2 map is read by pool2's backward only when the nibbles are off (DBX_POOL_IDX=0)
+        conv3_pool('conv2_2_1', 'a21', B['a22'].view(), B['p2'].view(), 128, 'a22', train and PI is None)
         conv3('conv3_1_1', 'p2', 'a31', 128, 256)
         conv3('conv3_2_1', 'a31', 'a32', 256, 256)
         c34 = B['fusion'].view(512, 256)
-        conv3('conv3_4_1', 'a32', None, 256, 256, dst_view=c34)       # writes fusion[:, 512:768]
-        pool(c34, B['p3'].view(), 'fusion')
+        conv3_pool('conv3_4_1', 'a32', c34, B['p3'].view(), 256, 'fusion', True)       # writes fusion[:, 512:768] and pool3
         conv3('conv4_1_1', 'p3', 'a41', 256, 512)
         conv3('conv4_2_1', 'a41', 'a42', 512, 512)
         conv3('conv4_3_1', 'a42', 'a43', 512, 512)

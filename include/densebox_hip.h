@@ -141,8 +141,10 @@ int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x, const void
 /* dbx_conv_forward with the 2x2 / stride 2 max pooling of its output done in the epilogue (conv1_2 -> pool1,
  * DenseBox.py:186-187): `ypool` (N x H/2 x W/2 x 64) receives exactly what dbx_maxpool2x2 would make of y; with
  * write_full == 0 only the pooled map is written (inference: nothing re-reads the full-resolution map).  Exists for the
- * problems dbx_conv_pool_fusable() returns 1 for -- 16-bit 3x3 / pad 1, 64 -> 64 channels on congruent frames, even H and W,
- * epilogue within BIAS | RELU (the halo-tile kernel); anything else is DBX_ERR_ARG and the caller runs the two calls. */
+ * problems dbx_conv_pool_fusable() returns 1 for -- 16-bit 3x3 / pad 1 on congruent frames, even H and W: 64 -> 64 channels with an
+ * epilogue within BIAS | RELU (the halo-tile kernel), or a layer the 8-phase kernels take (DBX_K_P8: conv2_2 -> pool2, conv3_4 ->
+ * pool3, DenseBox.py:191, :204) with a (BIAS |) RELU epilogue, `ypool` N x H/2 x W/2 x y->c; anything else is DBX_ERR_ARG and the
+ * caller runs the two calls. */
 int dbx_conv_pool_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y);
 int dbx_conv_forward_pool(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
                           const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* stream);

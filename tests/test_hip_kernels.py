@@ -152,6 +152,97 @@ def test_conv_p8_kernel(case, dtn):
     assert float(ty[:, -1].abs().sum()) == 0 and float(ty[:, :, -1].abs().sum()) == 0
 
 
+P8_POOL_CASES = [  # n, h, w, channels, y slot (c_off, extra channels behind): the layers with a MaxPool2d behind them (DenseBox.py:191, :204)
+    (16, 60, 60, 256, 0, 0),       # conv3_4-like, 225 tiles of 8 units
+    (20, 60, 60, 256, 512, 0),     # ... writing fusion[:, 512:768] (the engine's call): 7- and 8-unit tiles, a second tile per workgroup
+    (17, 50, 66, 256, 0, 64),      # W != H, image seams inside tiles, ragged last unit (56100 pixels)
+    (8, 120, 120, 128, 0, 0),      # conv2_2-like: the 512 x 128 tiles (conv3x3_p8w_kernel)
+    (9, 100, 132, 128, 0, 0),      # ... ragged last unit, W != H
+]
+
+
+@pytest.mark.parametrize('dtn', ['f16', 'bf16'])
+@pytest.mark.parametrize('case', P8_POOL_CASES)
+def test_conv_p8_pool_epilogue(case, dtn):
+    """The 2x2 max-pool in the 8-phase kernels' epilogue (dbx_conv_forward_pool_idx on conv2_2 / conv3_4 shapes): the full map is bitwise the
+    un-pooled call's, the pooled map and the arg-max nibbles bitwise what dbx_maxpool2x2_idx makes of that map, write_full = 0 leaves the
+    full map untouched, neighbouring channel slots and the frames stay as they were."""
+    if os.environ.get('DBX_CONV_VARIANT') or os.environ.get('DBX_P8') == '0' or os.environ.get('DBX_P8_POOL') == '0':
+        pytest.skip('this process forces another kernel')
+    n, h, w, c, yo, yx = case
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    g = torch.Generator(device='cpu').manual_seed(h * w + c)
+    x = torch.randn(n, c, h, w, generator=g).cuda()
+    wt = (torch.randn(c, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5).cuda()
+    b = torch.randn(c, generator=g).cuda() * 0.3
+    fx, tx, xv = framed(x, 1, tdt)
+    wp = pack(L, dt, wt, c, c)
+    d = ConvDesc(dt, 3, 3, 1, c, c, _lib.EPI_BIAS | _lib.EPI_RELU)
+
+    def out_view():
+        fy, ty, yv_all = framed(torch.zeros(n, yo + c + yx, h, w), 1, tdt)
+        return fy, ty, View(yv_all.ptr, n, h, w, 1, yv_all.ld, yo, c)
+
+    def pooled():
+        fp, tp, pv = framed(torch.zeros(n, c, h // 2, w // 2), 1, tdt)
+        return fp, tp, pv
+    nb = L.dbx_maxpool_idx_bytes(n, h, w, c)
+    fy, ty, yv = out_view()
+    assert L.dbx_conv_pool_fusable(C.byref(d), C.byref(xv), C.byref(yv)) == 1
+    plan = _lib.ConvPlan()
+    check(L.dbx_conv_plan(C.byref(d), C.byref(xv), C.byref(yv), C.byref(plan)))
+    assert plan.kernel == _lib.K_P8, plan.name
+    # the two calls
+    check(L.dbx_conv_forward(C.byref(d), C.byref(xv), ptr(wp), ptr(b), C.byref(yv), None, None, 0, stream_ptr()))
+    fp, tp, pv = pooled()
+    idx = torch.zeros(nb + 16, dtype=torch.uint8, device='cuda')
+    check(L.dbx_maxpool2x2_idx(dt, C.byref(yv), C.byref(pv), ptr(idx), stream_ptr()))
+    # one call, both maps + nibbles
+    fy2, ty2, yv2 = out_view()
+    fp2, tp2, pv2 = pooled()
+    idx2 = torch.zeros(nb + 16, dtype=torch.uint8, device='cuda')
+    check(L.dbx_conv_forward_pool_idx(C.byref(d), C.byref(xv), ptr(wp), ptr(b), C.byref(yv2), C.byref(pv2), 1, ptr(idx2), stream_ptr()))
+    torch.cuda.synchronize()
+    assert float(tp.float().abs().sum()) > 0 and int((idx & 3).sum()) > 0 and int((idx & 4).sum()) > 0
+    assert torch.equal(fy.view(torch.int16), fy2.view(torch.int16))
+    assert torch.equal(fp.view(torch.int16), fp2.view(torch.int16))
+    assert torch.equal(idx, idx2), int((idx != idx2).sum())
+    ref = F.max_pool2d(F.relu(F.conv2d(x.to(tdt).float(), wt.to(tdt).float(), b, padding=1)), 2)
+    got = tp2[:, 1:1 + h // 2, 1:1 + w // 2].permute(0, 3, 1, 2).float()
+    tol = 2e-2 if dtn == 'bf16' else 3e-3
+    assert torch.allclose(got, ref, rtol=tol, atol=tol), (got - ref).abs().max().item()
+    # the pooled map only (conv2_2 in a training step with nibbles, and in inference); without nibbles too
+    fy3, ty3, yv3 = out_view()
+    fp3, tp3, pv3 = pooled()
+    idx3 = torch.zeros(nb + 16, dtype=torch.uint8, device='cuda')
+    check(L.dbx_conv_forward_pool_idx(C.byref(d), C.byref(xv), ptr(wp), ptr(b), C.byref(yv3), C.byref(pv3), 0, ptr(idx3), stream_ptr()))
+    fy4, ty4, yv4 = out_view()
+    fp4, tp4, pv4 = pooled()
+    check(L.dbx_conv_forward_pool(C.byref(d), C.byref(xv), ptr(wp), ptr(b), C.byref(yv4), C.byref(pv4), 1, stream_ptr()))
+    torch.cuda.synchronize()
+    assert float(fy3.float().abs().sum()) == 0 and torch.equal(fp3.view(torch.int16), fp.view(torch.int16)) and torch.equal(idx3, idx)
+    assert torch.equal(fy4.view(torch.int16), fy.view(torch.int16)) and torch.equal(fp4.view(torch.int16), fp.view(torch.int16))
+    # the pooling backward driven by the fused call's nibbles equals the activation-reading one on the stored map
+    dy = torch.randn(n, c, h // 2, w // 2, generator=g).cuda()
+    fdy, tdy, dyv = framed(dy, 0, tdt)
+    fa, ta, dxa = framed(torch.zeros(n, c, h, w), 1, tdt)
+    fb, tb, dxb = framed(torch.zeros(n, c, h, w), 1, tdt)
+    yplain = View(yv.ptr, n, h, w, 1, yv.ld, yo, c)
+    check(L.dbx_maxpool2x2_bwd(dt, C.byref(yplain), C.byref(dyv), C.byref(dxa), 0, 1, stream_ptr()))
+    check(L.dbx_maxpool2x2_bwd_idx(dt, ptr(idx2), C.byref(dyv), C.byref(dxb), 0, 1, stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(fa.view(torch.int16), fb.view(torch.int16)) and float(tb.float().abs().sum()) > 0
+    if yo or yx:
+        assert float(ty2[..., :yo].abs().sum()) == 0 and float(ty2[..., yo + c:].abs().sum()) == 0
+    for t in (ty2, tp2, tp3):
+        assert float(t[:, 0].abs().sum()) == 0 and float(t[:, :, 0].abs().sum()) == 0
+        assert float(t[:, -1].abs().sum()) == 0 and float(t[:, :, -1].abs().sum()) == 0
+    # odd sizes: no fused path
+    fo, to, ov = framed(torch.zeros(2, c, h + 1, w), 1, tdt)
+    assert L.dbx_conv_pool_fusable(C.byref(d), C.byref(ov), C.byref(ov)) == 0
+
+
 WG_CASES = [  # n, h, w, cin (view), cin real, cout, k, pad
     (2, 20, 28, 64, 64, 64, 3, 1), (2, 24, 24, 8, 3, 64, 3, 1), (3, 17, 23, 64, 64, 128, 3, 1), (2, 12, 12, 128, 128, 128, 3, 1),
     (1, 30, 30, 256, 256, 512, 3, 1), (2, 15, 15, 768, 768, 512, 1, 0), (2, 16, 16, 512, 512, 8, 1, 0),
