@@ -13,7 +13,7 @@ def framed(n, h, c, pad=1):
     t = flat[guard:guard + n * hp * hp * c].view(n, hp, hp, c)
     t[:, pad:h + pad, pad:h + pad] = torch.randn((n, h, h, c), device='cuda').to(tdt)
     return flat, t
-N = 64
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 for name, H, ci, co, epi in [('heads fwd 768->2048 @60', 60, 768, 2048, _lib.EPI_BIAS | _lib.EPI_DROPHASH), ('Wc 256->2048 @60', 60, 256, 2048, _lib.EPI_BIAS | _lib.EPI_DROPHASH),
                              ('Wu 512->2048 @30', 30, 512, 2048, 0), ('dC 2048->256 @60', 60, 2048, 256, 0), ('dA 2048->512 @30', 30, 2048, 512, 0),
                              ('dgrad 2048->768 @60', 60, 2048, 768, 0),
