@@ -158,11 +158,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
     // pixel index -> (image, row, column): float estimate + one correction step (exact for p < 2^24)
     auto split0 = [&](int p, int& n, int& oy, int& ox) {
         n = (int)(((float)p + 0.5f) * t.inv_HW);
-        int r = p - n * t.HW;
+        int r = p - __mul24(n, t.HW);                              // (24-bit multiplies run at full rate; n, HW, W < 2^24: the host checks M)
         if (r < 0) { --n; r += t.HW; }
         if (r >= t.HW) { ++n; r -= t.HW; }
         oy = (int)(((float)r + 0.5f) * t.inv_W);
-        ox = r - oy * t.W;
+        ox = r - __mul24(oy, t.W);
         if (ox < 0) { --oy; ox += t.W; }
         if (ox >= t.W) { ++oy; ox -= t.W; }
     };
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                         const int pp = ok ? p : cur.p0;
                         int n, oy, ox;                                      // (divided out per row: carrying the coordinates across the rows spilled 10 registers here)
                         split(pp, n, oy, ox);
-                        const size_t yo = (size_t)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (size_t)a.y_ld;
+                        const unsigned yo = (__umul24(__umul24(n, a.y_hp) + oy + a.y_pad, a.y_wp) + ox + a.y_pad) * (unsigned)a.y_ld;      // (< 4 G elements: host check)
                         f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int nh = 0; nh < 2; ++nh) {
@@ -378,9 +378,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                     const int p = cur.p0 + row_index(cur.nf, mh, L.wr * 64 + mi * 16 + (lane & 15));
                     ok[mh][mi] = p < pend;
                     if (mi == 0) split(p < a.M ? p : a.M - 1, n, oy, ox); else advance16(p, n, oy, ox);
-                    yo[mh][mi] = (unsigned)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (unsigned)a.y_ld;
+                    yo[mh][mi] = (__umul24(__umul24(n, a.y_hp) + oy + a.y_pad, a.y_wp) + ox + a.y_pad) * (unsigned)a.y_ld;
                     if constexpr (EPIK == 2) {
-                        size_t go = (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld;
+                        size_t go = (size_t)(__umul24(__umul24(n, a.g_hp) + oy + a.g_pad, a.g_wp) + ox + a.g_pad) * (size_t)a.g_ld;
                         if (mi == 0) go0 = go;
                         if (!ok[mh][mi]) go = go0;                          // rows past the tile's end: any address that exists
 #pragma unroll
@@ -513,11 +513,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, c
     };
     auto split0 = [&](int p, int& n, int& oy, int& ox) {
         n = (int)(((float)p + 0.5f) * t.inv_HW);
-        int r = p - n * t.HW;
+        int r = p - __mul24(n, t.HW);                              // (24-bit multiplies run at full rate; n, HW, W < 2^24: the host checks M)
         if (r < 0) { --n; r += t.HW; }
         if (r >= t.HW) { ++n; r -= t.HW; }
         oy = (int)(((float)r + 0.5f) * t.inv_W);
-        ox = r - oy * t.W;
+        ox = r - __mul24(oy, t.W);
         if (ox < 0) { --oy; ox += t.W; }
         if (ox >= t.W) { ++oy; ox -= t.W; }
     };
@@ -648,9 +648,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, c
                         ok[m2][mi] = p < pend;
                         int n, oy, ox;
                         split(ok[m2][mi] ? p : cur.p0, n, oy, ox);
-                        yo[m2][mi] = (unsigned)((n * a.y_hp + oy + a.y_pad) * a.y_wp + ox + a.y_pad) * (unsigned)a.y_ld;
+                        yo[m2][mi] = (__umul24(__umul24(n, a.y_hp) + oy + a.y_pad, a.y_wp) + ox + a.y_pad) * (unsigned)a.y_ld;
                         if constexpr (EPIK == 2) {
-                            const size_t go = (size_t)((n * a.g_hp + oy + a.g_pad) * a.g_wp + ox + a.g_pad) * (size_t)a.g_ld;
+                            const size_t go = (size_t)(__umul24(__umul24(n, a.g_hp) + oy + a.g_pad, a.g_wp) + ox + a.g_pad) * (size_t)a.g_ld;
                             gt[m2][mi] = *(const u32x4*)(gbase + go + nc);
                         }
                     }
