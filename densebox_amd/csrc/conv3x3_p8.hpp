@@ -270,6 +270,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                         w2f[nh] = *(const u32x4*)(a.w2f + ((size_t)l15 * (size_t)(a.ntile_n * 256) + cur.n0 + nh * 128 + cl) * ES);
                 }
                 char* const red = smem + p8::LDS_BYTES + L.wr * 16384;
+                const f32x4 two4 = {2.f, 2.f, 2.f, 2.f};
 #pragma unroll
                 for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                             f32x4 v[2];
 #pragma unroll
                             for (int ni = 0; ni < 2; ++ni) {
-                                v[ni] = acc.v[mh][nh][mi][ni] * 2.f + bias[nh][ni];
+                                v[ni] = __builtin_elementwise_fma(acc.v[mh][nh][mi][ni], two4, bias[nh][ni]);      // (one v_pk_fma_f32 per pair: the compiler's own choice is x + x, then + bias)
                             }
                             // a dropped element is cleared by ANDing with the sign-extended one-bit field of the hash (p8_keep<bit>: the bit
                             // position is an immediate of v_bfe_i32)
