@@ -258,6 +258,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
             else p8::ktiles<T, 16, FLAGS, MI1>(acc, L, nkt, stA, stB);
             p8::tile_end<FLAGS>(L);
             if constexpr (EPIK == 1) {
+#if defined(P8_ABL) && (P8_ABL & 4)
+                if (a.drop_seed != 0x7fffffffu) return;                                                   // lab: no epilogue at all (timing only)
+#endif
                 // ---- heads forward: 2 (acc + bias) behind the keep bits, rounded, stored; the second convs on the stored chunks
                 const int pend = cur.p0 + cur.nf * 32 < a.M ? cur.p0 + cur.nf * 32 : a.M;
                 T* const ybase = (T*)a.y + cur.n0;
@@ -286,7 +289,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
 #pragma unroll
                         for (int nh = 0; nh < 2; ++nh) {
                             // one hash covers the wave's 32 channels of this pixel; lane row g holds bits 4 g .. of each 16-channel fragment
+#if defined(P8_ABL) && (P8_ABL & 2)
+                            const unsigned hs = 0xffffffffu;                                                  // lab: no hash (timing only)
+#else
                             const unsigned hs = dbx_drop_hash32(a.drop_seed, (unsigned)pp, (unsigned)(cur.n0 + nh * 128 + L.wc * 32) >> 5) >> (4 * g4);
+#endif
                             f32x4 v[2];
 #pragma unroll
                             for (int ni = 0; ni < 2; ++ni) {
@@ -298,7 +305,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                             v[1].x = p8_keep<16>(v[1].x, hs); v[1].y = p8_keep<17>(v[1].y, hs); v[1].z = p8_keep<18>(v[1].z, hs); v[1].w = p8_keep<19>(v[1].w, hs);
                             const u32x4 o = pair_exchange<T>(v[0], v[1]);
                             if (a.w2f) p8::Mma16<T>::run(w2f[nh], o, acc2);
+#if defined(P8_ABL) && (P8_ABL & 1)
+                            if (ok && o.x == 0x12345678u) *(u32x4*)(ybase + yo + nh * 128 + cl) = o;        // lab: no stores (timing only)
+#elif defined(P8_HID_NT)
+                            if (ok) __builtin_nontemporal_store(o, (u32x4*)(ybase + yo + nh * 128 + cl));
+#else
                             if (ok) *(u32x4*)(ybase + yo + nh * 128 + cl) = o;
+#endif
                         }
                         // rows 4 g .. 4 g + 3 of the second convs' outputs for pixel l15: only g < 2 (k <= 8) carries anything
                         if (a.w2f && g4 < 2) *(f32x4*)(red + ((L.wc * 8 + mh * 4 + mi) * 32 + (lane & 31)) * 16) = acc2;
