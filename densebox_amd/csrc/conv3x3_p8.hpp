@@ -75,6 +75,7 @@ struct P8Args {
     int nkt;             // K tiles: taps * cin / 64 (even)
     int HW, W;           // output pixels per image / per row (EPIK 3: POOLED pixels per image / per row: the enumeration is window-major)
     float inv_HW, inv_W;
+    unsigned long long* tstamp;  // lab builds (-DP8_TILE_STAMPS): per-tile stamp table, else null
     unsigned long long* stamp;   // lab builds (-DDBX_P8_STAMP): {first workgroup in, last workgroup out} of this launch in s_memrealtime ticks (10 ns), else null
 };
 
@@ -99,11 +100,33 @@ extern "C" int dbx_lab_p8_stamps(unsigned long long* out, int max_n) {
     if (n > 0 && hipMemcpy(out, g_p8_stamps, sizeof(unsigned long long) * 2 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return n;
 }
+// -DP8_TILE_STAMPS (with -DDBX_P8_STAMP): per-tile stamps of the heads forward (EPIK 1): workgroup 0 .. 255's wave 0 writes {tile top, K loop done,
+// chunks done, reduction done} of each of its tiles; dbx_lab_p8_tile_stamps copies the table out (tools/gpu_p8_tile_stamps.py)
+#ifdef P8_TILE_STAMPS
+static unsigned long long* g_p8_tile_stamps = nullptr;
+constexpr int P8_TILE_STAMP_MAX = 16384;
+static unsigned long long* p8_tile_stamp_table() {
+    if (!g_p8_tile_stamps) {
+        if (hipMalloc(&g_p8_tile_stamps, sizeof(unsigned long long) * 4 * P8_TILE_STAMP_MAX) != hipSuccess) return nullptr;
+        (void)hipMemset(g_p8_tile_stamps, 0, sizeof(unsigned long long) * 4 * P8_TILE_STAMP_MAX);
+    }
+    return g_p8_tile_stamps;
+}
+extern "C" int dbx_lab_p8_tile_stamps(unsigned long long* out, int max_items) {
+    const int n = max_items < P8_TILE_STAMP_MAX ? max_items : P8_TILE_STAMP_MAX;
+    if (!g_p8_tile_stamps || hipMemcpy(out, g_p8_tile_stamps, sizeof(unsigned long long) * 4 * n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+#define P8_TSTAMP(t, item, k) do { if (EPIK == 1 && (t).tstamp && threadIdx.x == 0 && (item) < P8_TILE_STAMP_MAX) (t).tstamp[4 * (item) + (k)] = wall_clock64(); } while (0)
+#else
+#define P8_TSTAMP(t, item, k) do { } while (0)
+#endif
 #define P8_STAMP_IN(t) do { if ((t).stamp && threadIdx.x == 0) atomicMin((t).stamp, wall_clock64()); } while (0)
 #define P8_STAMP_OUT(t) do { if ((t).stamp && threadIdx.x == 0) atomicMax((t).stamp + 1, wall_clock64()); } while (0)
 #else
 #define P8_STAMP_IN(t) do { } while (0)
 #define P8_STAMP_OUT(t) do { } while (0)
+#define P8_TSTAMP(t, item, k) do { } while (0)
 #endif
 
 // EPIK 0: bias and / or ReLU by the arguments' flags; EPIK 2: the ReLU gate of the data gradients, no bias (its own instantiation: the gate
@@ -241,6 +264,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
         const int nxt_item = item + G;
         const bool more = nxt_item < t.items;
         if (more) { nxt = tile_of(nxt_item); a_offsets(nxt, vnxt); }          // last tile: the stream re-fetches its own start (never read)
+        P8_TSTAMP(t, item, 0);
         p8::zero<16>(acc);
         if (EPIK != 2 && cur.n0 != bias_n0) {
             bias_n0 = cur.n0;
@@ -255,8 +279,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
             constexpr int MI1 = decltype(MI1_)::value;
             p8::tile_begin<FLAGS>(L);
             if constexpr (FLAGS & p8::FL_P4) p8::ktiles4<T, FLAGS, MI1>(acc, L, nkt, stA, stB);
+#ifdef P8_KT_STAMPS
+            else p8::ktiles<T, 16, FLAGS, MI1>(acc, L, nkt, stA, stB, [&](int kt) {
+                if (EPIK == 1 && t.tstamp && threadIdx.x == 0 && item < 1024 && kt < 16) t.tstamp[4 * P8_TILE_STAMP_MAX / 2 + item * 8 + (kt >> 1)] = wall_clock64(); });
+#else
             else p8::ktiles<T, 16, FLAGS, MI1>(acc, L, nkt, stA, stB);
+#endif
             p8::tile_end<FLAGS>(L);
+            P8_TSTAMP(t, item, 1);
             if constexpr (EPIK == 1) {
 #if defined(P8_ABL) && (P8_ABL & 4)
                 if (a.drop_seed != 0x7fffffffu) return;                                                   // lab: no epilogue at all (timing only)
@@ -317,6 +347,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                         if (a.w2f && g4 < 2) *(f32x4*)(red + ((L.wc * 8 + mh * 4 + mi) * 32 + (lane & 31)) * 16) = acc2;
                     }
                 }
+                P8_TSTAMP(t, item, 2);
                 if (a.w2f) {
                     // the group's four waves, summed in wave order; wave wc finishes fragments 2 wc and 2 wc + 1.  The barrier is the
                     // whole workgroup's (every wave runs the same barrier sequence one phase apart: the stagger is unchanged)
@@ -335,6 +366,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
                         }
                     }
                 }
+                P8_TSTAMP(t, item, 3);
                 return;
             }
             if constexpr (EPIK == 3) {
@@ -484,11 +516,18 @@ static int launch_conv_p8(const ConvArgs& a, hipStream_t s) {
         t.HW = a.HoWo; t.W = a.Wo;
         if (EPIK == 3) { t.HW = a.HoWo / 4; t.W = a.Wo / 2; }          // window-major enumeration: the pooled map's dims
         t.inv_HW = 1.0f / (float)t.HW; t.inv_W = 1.0f / (float)t.W;
+        t.tstamp = nullptr;
+#ifdef P8_TILE_STAMPS
+        if (EPIK == 1) t.tstamp = p8_tile_stamp_table();
+#endif
         t.stamp = nullptr;
 #ifdef DBX_P8_STAMP
         t.stamp = p8_next_stamp();
 #endif
-        const int grid = t.items < ncu ? t.items : ncu;
+        int grid = t.items < ncu ? t.items : ncu;
+#ifdef P8_TILE_STAMPS
+        if (const char* e = getenv("DBX_P8_MAXWG")) { const int g = atoi(e); if (g > 0 && g < grid) grid = g; }      // lab: fewer CUs at work (is a stall per-CU or chip-wide?)
+#endif
         hipLaunchKernelGGL((conv3x3_p8_kernel<T, KS, FLAGS, EPIK>), dim3(grid), dim3(512), LDS, s, a, t);
         DBX_LAUNCH_CHECK();
     }
@@ -736,6 +775,7 @@ static int launch_conv_p8w(const ConvArgs& a, hipStream_t s) {
         t.HW = a.HoWo; t.W = a.Wo;
         if (EPIK == 3) { t.HW = a.HoWo / 4; t.W = a.Wo / 2; }          // window-major enumeration: the pooled map's dims
         t.inv_HW = 1.0f / (float)t.HW; t.inv_W = 1.0f / (float)t.W;
+        t.tstamp = nullptr;
         t.stamp = nullptr;
 #ifdef DBX_P8_STAMP
         t.stamp = p8_next_stamp();

@@ -159,8 +159,9 @@ __device__ __forceinline__ void finish(const Lanes<MF>& L) {
 
 // MI1: 16-row fragments per wave in the SECOND m half (16x16x32 only): 4 = 256-row tile, 3 = 224 rows (LDS rows 48..63 of each wave's
 // 64 of half-tile A[1] are loaded and ignored): persistent workgroups balance their tile heights with it.
-template <typename T, int MF, int FLAGS, int MI1 = (MF == 16 ? 4 : 2), typename SA, typename SB>
-__device__ __forceinline__ void ktiles(Acc<MF>& acc, const Lanes<MF>& L, int nkt, SA stA, SB stB) {
+struct NoKtCb { __device__ __forceinline__ void operator()(int) const {} };        // lab: a callback in front of every pair of K tiles (stamps)
+template <typename T, int MF, int FLAGS, int MI1 = (MF == 16 ? 4 : 2), typename SA, typename SB, typename CB = NoKtCb>
+__device__ __forceinline__ void ktiles(Acc<MF>& acc, const Lanes<MF>& L, int nkt, SA stA, SB stB, CB cb = CB{}) {
     constexpr bool PRIO = FLAGS & FL_PRIO, SAFE = FLAGS & FL_SAFE;
     static_assert(MF == 16 ? (MI1 >= 2 && MI1 <= 4) : MI1 == 2, "tile height");
     u32x4 af[8], bf[2][4];
@@ -238,6 +239,7 @@ __device__ __forceinline__ void ktiles(Acc<MF>& acc, const Lanes<MF>& L, int nkt
     };
     for (int kt = 0; kt < nkt; kt += 2) {
         using pipe::IC;
+        cb(kt);
         phase(IC<1>{}, IC<0>{}, kt); phase(IC<2>{}, IC<0>{}, kt); phase(IC<3>{}, IC<0>{}, kt); phase(IC<4>{}, IC<0>{}, kt);
         phase(IC<1>{}, IC<1>{}, kt + 1); phase(IC<2>{}, IC<1>{}, kt + 1); phase(IC<3>{}, IC<1>{}, kt + 1); phase(IC<4>{}, IC<1>{}, kt + 1);
     }
