@@ -236,6 +236,8 @@ def test_eval_and_train_forward_agree_through_fused_pool(golden, monkeypatch):
     """Inference and training both skip the full-resolution conv1_2 map (dbx_conv_forward_pool_idx writes the pooled output, training
     also the arg-max nibbles its pooling backward reads); DBX_POOL_IDX=0 brings the map and the activation-reading backward back.
     The pooled activation that everything downstream reads is the same bit for bit in all three."""
+    if os.environ.get('DBX_POOL_IDX') == '0':
+        pytest.skip('this process runs without the arg-max nibbles: the default plan this test starts from does not exist')
     g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', 'f16')
     xs = x[:n].cuda()
     eng = net.engine()
