@@ -1,5 +1,6 @@
 """GPU parity of the full training step (forward -> fused loss -> HIP backward -> fused SGD) against the
 gradients / parameter updates captured from the reference's own training loops."""
+import os
 import numpy as np
 import pytest
 import torch
