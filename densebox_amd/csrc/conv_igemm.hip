@@ -2077,10 +2077,14 @@ extern "C" int dbx_pack_weight(int32_t dtype, int32_t mode, const float* w_oihw,
 // (d_out W2) generated in registers (heads_gen.hpp) -- dbx_conv_forward(d_hid, W1^T image, DBX_EPI_GATE) without d_hid in memory.
 // d_out / w2 / k / use_hash / drop_seed as for dbx_heads1_wgrad_gen; w1t_frag: dbx_pack_weight mode 5 image of W1 restricted to the
 // 256 input channels of y (rows_pad 256, cin_pad 512 nh); y, gate: 256-channel views of the same pixels (any padding).
+int dbx_internal_heads1_dgrad_gen_f32(const dbx_view* d_out, const float* const* w2, const int32_t* k, int nh, int use_hash, unsigned seed,
+                                      const void* w1t_plain, const dbx_view* y, const dbx_view* gate, hipStream_t s);
 template <typename T>
 static int heads1_dgrad_gen_t(const dbx_view* d_out, const float* const* w2, const int32_t* k, int nh, int use_hash, unsigned seed, const void* w1t_frag,
                               const dbx_view* y, const dbx_view* gate, hipStream_t s) {
-    if constexpr (sizeof(T) != 2) { dbx_set_error("heads1_dgrad_gen: 16-bit compute types only"); return DBX_ERR_DTYPE; }
+    // fp32: the parity suite's reference instantiation (heads_ref_f32.hip); w1t_frag is then the PLAIN data-gradient image (dbx_pack_weight
+    // mode 1, rows_pad = y's channels, cin_pad = 512 nh: rows of 512 nh floats)
+    if constexpr (sizeof(T) != 2) return dbx_internal_heads1_dgrad_gen_f32(d_out, w2, k, nh, use_hash, seed, w1t_frag, y, gate, s);
     else {
         DBX_REQUIRE(nh >= 1 && nh <= 4 && d_out->pad == 0 && d_out->n == y->n && d_out->h == y->h && d_out->w == y->w && gate->n == y->n &&
                     gate->h == y->h && gate->w == y->w, "heads1_dgrad_gen: d_out (compact), y and gate are maps of the same pixels");

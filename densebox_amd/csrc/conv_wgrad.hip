@@ -2177,10 +2177,13 @@ extern "C" int dbx_conv_wgrad_slice(int32_t dtype, const dbx_view* dz, const dbx
 // output gradients (pad 0, one slot of slot_c >= 8 channels per head, channels >= k[i] zero); x: the 1x1 convs' input on its padded
 // frame (pad >= 1, >= 32 columns); w2[i]: fp32 [k[i]][512].  use_hash / drop_seed: the forward's hash dropout (0: no dropout).
 // Scratch: dbx_conv_wgrad_scratch_bytes for a dz view of 512 * nh channels congruent with x.
+int dbx_internal_heads1_wgrad_gen_f32(const dbx_view* d_out, const dbx_view* x, const float* const* w2, const int32_t* k, int nh, int use_hash,
+                                      unsigned seed, int ci, float* dw, int ci_total, int ci_off, float* db, hipStream_t s);
 template <typename T>
 static int heads1_wgrad_gen_t(const dbx_view* d_out, const dbx_view* x, const float* const* w2, const int32_t* k, int nh, int use_hash, unsigned seed,
                               int ci, float* dw, int ci_total, int ci_off, float* db, void* scratch, hipStream_t s) {
-    if constexpr (sizeof(T) != 2) { dbx_set_error("heads1_wgrad_gen: 16-bit compute types only"); return DBX_ERR_DTYPE; }
+    // fp32: the parity suite's reference instantiation (heads_ref_f32.hip; scratch unused)
+    if constexpr (sizeof(T) != 2) return dbx_internal_heads1_wgrad_gen_f32(d_out, x, w2, k, nh, use_hash, seed, ci, dw, ci_total, ci_off, db, s);
     else {
         DBX_REQUIRE(nh >= 1 && nh <= 4 && d_out->pad == 0 && d_out->n == x->n && d_out->h == x->h && d_out->w == x->w && x->pad >= 1,
                     "heads1_wgrad_gen: d_out is the compact map of x's pixels, x a padded frame");
@@ -2201,6 +2204,7 @@ static int heads1_wgrad_gen_t(const dbx_view* d_out, const dbx_view* x, const fl
 }
 // 1 when dbx_heads1_wgrad_gen can run for x (the wide 1x1 kernel on a padded frame of >= 32 columns)
 extern "C" int dbx_heads1_wgrad_gen_ok(int32_t dtype, const dbx_view* x, int32_t nh) {
+    if (dtype == DBX_F32) return (x && nh >= 1 && nh <= 4) ? 1 : 0;        // (the fp32 reference instantiation takes any frame)
     if (!x || (dtype != DBX_F16 && dtype != DBX_BF16) || nh < 1 || nh > 4 || x->pad < 1) return 0;
     dbx_view dz = *x;
     dz.c = dz.ld = 512 * nh; dz.c_off = 0;

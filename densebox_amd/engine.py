@@ -70,13 +70,16 @@ class Plan:
     @staticmethod
     def env_flags():
         """The environment switches that decide which buffers a plan holds (part of the plan cache key)."""
-        return tuple(os.environ.get(k, '1') != '0' for k in ('DBX_LIN_BWD', 'DBX_REFINE_LINEAR', 'DBX_POOL_IDX', 'DBX_HEADS_GEN'))
+        return tuple(os.environ.get(k, '1') != '0' for k in ('DBX_LIN_BWD', 'DBX_REFINE_LINEAR', 'DBX_POOL_IDX', 'DBX_HEADS_GEN')) + \
+            (os.environ.get('DBX_F32_LIN', '0') == '1',)
 
     def __init__(self, kind, n, h, w, dtype_id, device, train):
         self.kind, self.n, self.h, self.w, self.dtype_id, self.train = kind, n, h, w, dtype_id, train
         self.flags = Plan.env_flags()
-        lin_bwd, lin_refine, use_idx, heads_gen = self.flags
-        lin_bwd = lin_bwd and dtype_id != _lib.F32
+        lin_bwd, lin_refine, use_idx, heads_gen, f32_lin = self.flags
+        # fp32 keeps the full-resolution heads backward unless DBX_F32_LIN=1 (parity suite: the 16-bit step's structure -- backward by linearity
+        # of the up-sampling, hidden gradient generated in its consumers -- on the exact-fp32 kernels, against the reference-captured gradients)
+        lin_bwd = lin_bwd and (dtype_id != _lib.F32 or f32_lin)
         es = _lib.ESIZE[dtype_id]
         self.cin0 = 16 // es                      # conv1_1 input channels padded to one 16-byte chunk
         # refine branch (cat(landmarks, score) -> pool -> 3x3 -> 5x5 -> bilinear -> 1x1; 61 MMAC per patch) runs in the compute type.
@@ -134,10 +137,15 @@ class Plan:
             # (the generating kernels' own limits, checked by DBX_REQUIRE at backward time: < 2^24 pixels, d_out below 2 GiB, k <= 8 per head --
             #  a plan outside them keeps the hidden gradient in memory instead of failing in backward_raw)
             gen_fits = n * h4 * w4 < (1 << 24) and n * h4 * w4 * self.crf * nh * es < (1 << 31) and self.crf <= 8
-            self.heads_gen = bool(heads_gen and lin_bwd and gen_fits and
-                                  L.dbx_head2_backward_up_fused(dtype_id, C.byref(B['hid'].view()), C.byref(B['d_g44'].view())) and
-                                  L.dbx_heads1_wgrad_gen_ok(dtype_id, C.byref(B['fusion'].view(512, 256)), nh))
-            if not self.heads_gen:
+            if dtype_id == _lib.F32:
+                # (DBX_F32_LIN=1: the two consumers run their fp32 reference instantiations; dbx_head2_backward_up has no fp32 form that leaves
+                #  d_hid out, so the buffer exists -- and is poisoned behind that call, see backward_raw)
+                self.heads_gen = bool(heads_gen and lin_bwd)
+            else:
+                self.heads_gen = bool(heads_gen and lin_bwd and gen_fits and
+                                      L.dbx_head2_backward_up_fused(dtype_id, C.byref(B['hid'].view()), C.byref(B['d_g44'].view())) and
+                                      L.dbx_heads1_wgrad_gen_ok(dtype_id, C.byref(B['fusion'].view(512, 256)), nh))
+            if not self.heads_gen or dtype_id == _lib.F32:
                 add('d_hid', h4, w4, 512 * nh, pad=1)     # congruent with 'fusion'
             if rf_convs:
                 add('d_rfo', h4, w4, self.crf, pad=0)
@@ -222,6 +230,9 @@ class Engine:
         self._tables = {}          # (dtype, train) -> (device job table, count, max_elems)
         self._wsig = None
         self._plans_conv = {}      # problem signature -> (kernel id, name, fragment-order weights?) from dbx_conv_plan
+        # lab hook (tools/gpu_layer_error_budget.py): called as act_hook(buffer name, plan) right behind the launch that produced the buffer,
+        # on the launch stream -- e.g. to round ONE fp32 activation to 16 bits in place.  None in every product / test path.
+        self.act_hook = None
 
     def grad_order(self):
         """Parameter names in the order backward_raw() finishes their gradients (deepest first)."""
@@ -388,7 +399,7 @@ class Engine:
             elif which == 'ba' and 'd_g44' in B and dt != _lib.F32:
                 r = self.conv_plan(dt, B['d_g44'].view(), B['d_a44'].view(), 1, 1, 0, 512 * nh, 512, _lib.EPI_GATE)[2]
             elif which == 'bc' and getattr(P, 'heads_gen', False):
-                r = True                                   # dbx_heads1_dgrad_gen takes the fragment-order image
+                r = dt != _lib.F32                         # dbx_heads1_dgrad_gen takes the fragment-order image (its fp32 reference form the plain one)
             elif which == 'bc' and 'd_hid' in B and dt != _lib.F32:
                 r = self.conv_plan(dt, B['d_hid'].view(), B['d_c34'].view(), 1, 1, 0, 512 * nh, 256, _lib.EPI_GATE)[2]
             elif which in ('ba', 'bc'):
@@ -709,6 +720,12 @@ class Engine:
             check(L.dbx_nchw_to_framed(dt, ptr(Xf), 3, C.byref(B['x0'].view()), s))
         RELU = _lib.EPI_BIAS | _lib.EPI_RELU
 
+        def hook(*names):
+            if self.act_hook is not None:
+                for nm in names:
+                    self.act_hook(nm, P)
+        hook('x0')
+
         def conv3(stem, src, dst, cin, cout, dst_view=None):
             cin_pad = P.cin0 if cin == 3 else cin
             frag = self._frag(P, dt, stem, 'f')
@@ -726,6 +743,7 @@ class Engine:
                 check(L.dbx_maxpool2x2(dt, C.byref(xv), C.byref(yv), s))
 
         conv3('conv1_1_1', 'x0', 'a11', 3, 64)
+        hook('a11')
         d12 = ConvDesc(dt, 3, 3, 1, 64, 64, RELU, 0)
         a11v, a12v, p1v = B['a11'].view(), B['a12'].view(), B['p1'].view()
         if L.dbx_conv_pool_fusable(C.byref(d12), C.byref(a11v), C.byref(a12v)):
@@ -747,6 +765,7 @@ class Engine:
                 raise RuntimeError('conv1_2 + pool1 not fusable on a plan without a full-resolution conv1_2 map')
             conv3('conv1_2_1', 'a11', 'a12', 64, 64)
             pool(a12v, p1v, 'a12')
+        hook('p1')              # (rounding commutes with the max: the pooled map stands for conv1_2's output)
         def conv3_pool(stem, src, yv, pv, c, key, keep_full):
             """3x3 conv + bias + ReLU with the following MaxPool2d(2, 2) in the 8-phase kernels' epilogue when the library takes it (16-bit,
             even H, W): the pooling kernel's re-read of the map goes away, and so does the map itself when nothing else reads it (a22:
@@ -769,22 +788,32 @@ class Engine:
                              'flops': 2.0 * yv.n * yv.h * yv.w * 9 * c * c, 'start': ev0, 'end': ev1})
 
         conv3('conv2_1_1', 'p1', 'a21', 64, 128)
+        hook('a21')
         # the full conv2_2 map is read by pool2's backward only when the nibbles are off (DBX_POOL_IDX=0)
         conv3_pool('conv2_2_1', 'a21', B['a22'].view(), B['p2'].view(), 128, 'a22', train and PI is None)
+        hook('p2')
         conv3('conv3_1_1', 'p2', 'a31', 128, 256)
+        hook('a31')
         conv3('conv3_2_1', 'a31', 'a32', 256, 256)
+        hook('a32')
         c34 = B['fusion'].view(512, 256)
         conv3_pool('conv3_4_1', 'a32', c34, B['p3'].view(), 256, 'fusion', True)       # writes fusion[:, 512:768] and pool3
+        hook('c34', 'p3')
         conv3('conv4_1_1', 'p3', 'a41', 256, 512)
+        hook('a41')
         conv3('conv4_2_1', 'a41', 'a42', 512, 512)
+        hook('a42')
         conv3('conv4_3_1', 'a42', 'a43', 512, 512)
+        hook('a43')
         conv3('conv4_4_1', 'a43', 'a44', 512, 512)
+        hook('a44')
         # eval: the folded heads are linear in fusion = [up(a44); c34] and have only sum(k) outputs, so W [up(a44); c34] = up(W_a a44) + W_c c34:
         # the conv4_4 part runs on conv4_4's own grid and its 17 fp32 planes are up-sampled instead of 512 activation channels
         # (DBX_EVAL_LINEAR=0: up-sample the activations and run one 768-channel GEMM, as training must)
         lin_eval = not train and os.environ.get('DBX_EVAL_LINEAR', '1') != '0'
         if not lin_eval:
             check(L.dbx_upsample_bilinear(dt, C.byref(B['a44'].view()), C.byref(B['fusion'].view(0, 512)), s))
+            hook('ups')
 
         heads = _HEADS[kind]
         nh = len(heads)
@@ -975,7 +1004,7 @@ class Engine:
         """Heads backward by linearity of the bilinear up-sampling (16-bit types): W [up(a44); c34] = up(W_a a44) + W_c c34, so the
         conv4_4 part of the 768 -> 512 nh GEMM's data and weight gradients runs on conv4_4's 30x30 grid (a quarter of the pixels)
         after ONE transposed up-sampling of the hidden gradient.  DBX_LIN_BWD=0 keeps the full-resolution GEMMs."""
-        return dt != _lib.F32 and os.environ.get('DBX_LIN_BWD', '1') != '0'
+        return (dt != _lib.F32 or os.environ.get('DBX_F32_LIN', '0') == '1') and os.environ.get('DBX_LIN_BWD', '1') != '0'
 
     def _d_hid(self, P):
         """The hidden-gradient buffer; plans whose heads backward generates it hold none: made on first use (injected masks, side streams)."""
@@ -1162,7 +1191,7 @@ class Engine:
         # the hidden gradient d_hid = keep * (d_out W2): generated inside its two 60x60 consumers (no 944 MB map written and read twice) when
         # the plan holds no buffer for it and nothing needs it in memory (an injected dropout mask, the side-stream schedule do)
         gen = bool(getattr(P, 'heads_gen', False) and lin and side is None and mask_p is None)
-        if gen:
+        if gen and dt != _lib.F32:
             dhid_v = View(None, hv.n, hv.h, hv.w, 1, 512 * nh, 0, 512 * nh)     # "not in memory" for dbx_head2_backward_up
         else:
             dhid_v = self._d_hid(P).view()
@@ -1183,6 +1212,11 @@ class Engine:
                                           (C.c_void_p * nh)(*[t.data_ptr() for t in dw2]), (C.c_void_p * nh)(*[t.data_ptr() for t in db2]),
                                           ptr(self._h2_scratch), C.byref(B['d_g44'].view()), s))
             up_done = True
+            if gen and dt == _lib.F32:
+                # fp32 parity runs of the generating structure: d_hid had to be written (no fp32 form of the call leaves it out); nothing behind
+                # this point may read it -- a consumer that did would return NaN gradients
+                bh = P.B['d_hid']
+                P.ws[bh.off:bh.off + bh.bytes].view(torch.float32).fill_(float('nan'))
         else:       # one pass over the pixels: the d_hid write overlaps the hid read
             check(L.dbx_head2_backward(dt, C.byref(B['d_out'].view()), C.byref(hv), (C.c_void_p * nh)(*[w.data_ptr() for w in w2s]), ks, nh,
                                        C.byref(dhid_v), mask_p, 512 * nh, hash_on, hash_seed,
@@ -1233,7 +1267,7 @@ class Engine:
                     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     ev0.record()
                 check(L.dbx_heads1_dgrad_gen(dt, C.byref(B['d_out'].view()), w2p, ks, nh, hash_on, hash_seed,
-                                             ptr(self._w_heads1_bwd_part(dt, 'c', frag=True)), C.byref(B['d_c34'].view()), C.byref(c34), s))
+                                             ptr(self._w_heads1_bwd_part(dt, 'c', frag=dt != _lib.F32)), C.byref(B['d_c34'].view()), C.byref(c34), s))
                 if prof is not None:
                     ev1.record()
                     prof.append({'kernel': 'heads1_dgrad_gen_kernel<%s>' % ('f16', 'bf16', 'f32')[dt],

@@ -224,6 +224,9 @@ int dbx_head2_backward_up(int32_t dtype, const dbx_view* d_out, const dbx_view* 
  *     rows_pad 256, cin_pad 512 nh).
  * d_out: the compact [N, H, W] map (pad 0) with one slot of >= 8 channels per head, channels >= k[i] zero; w2[i]: fp32 [k[i]][512].
  * Results equal the in-memory forms up to fp32 summation order (W2 representable in the compute dtype) / its rounding (otherwise).
+ * DBX_F32 (round 6): plain one-thread-per-output reference instantiations of the two generators (csrc/heads_ref_f32.hip) so that the
+ * exact-fp32 path can run the 16-bit step's call structure against the reference-captured gradients; there d_out slots may be any
+ * width >= k, x / y / gate any frames, w1t_frag is the PLAIN dbx_pack_weight mode 1 image (rows of 512 nh floats) and scratch is unused.
  * (Heads: DenseBox.py:158-162, :174-178; their backward is autograd's in the reference.) */
 int dbx_head2_backward_up_fused(int32_t dtype, const dbx_view* hid, const dbx_view* d_g44);
 int dbx_heads1_wgrad_gen_ok(int32_t dtype, const dbx_view* x, int32_t nh);

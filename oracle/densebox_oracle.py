@@ -253,7 +253,8 @@ def hard_negatives(loss, gt, k):
 
 # ============================================================================ full loss (a9-a15)
 def loss_step(kind, outs, bbox, vertices=None, labels=None, rand_neg=None, lm_rand_neg=None,
-              lambda_loc=3.0, lambda_det=1.0, lambda_lm=0.5, batch_global=None, positive_num_global=None):
+              lambda_loc=3.0, lambda_det=1.0, lambda_lm=0.5, batch_global=None, positive_num_global=None,
+              hard_neg=None, lm_hard_neg=None):
     """The inline loss section of the three training loops as one function.
 
       kind='DenseBox'      : train_online            DenseBox.py:2843-2918
@@ -262,6 +263,10 @@ def loss_step(kind, outs, bbox, vertices=None, labels=None, rand_neg=None, lm_ra
 
     outs: tuple of torch tensors in the net's output order (may require grad).
     rand_neg [N,half], lm_rand_neg [4,N,1]: the np.random.choice draws (:2089-2094, :2133-2138).
+    hard_neg [N,half] / lm_hard_neg [4,N,1] (tests of the 16-bit paths only): the hard-negative indices to use INSTEAD of this function's
+    own top-k.  A 16-bit forward ranks two negatives whose losses differ in the 4th digit the other way round -- a legitimate choice by its
+    own values (tests/test_hip_loss.py pins the selection rule itself bit-exactly) that would otherwise show up as a whole pixel's
+    difference in every gradient; res['hard_own'] / res['lm_hard_own'] still carry this function's own selection for the caller to compare.
     Returns dict(loss=<0-d torch tensor>, masks, indices, gts).
     """
     N = outs[0].shape[0]
@@ -284,7 +289,8 @@ def loss_step(kind, outs, bbox, vertices=None, labels=None, rand_neg=None, lm_ra
     pos = nonzero4(gt)
     P = pos.shape[0] if positive_num_global is None else positive_num_global
     neg_num, half = neg_counts(P, N if batch_global is None else batch_global)
-    hard = hard_negatives(cls_loss.detach().numpy(), gt, half)
+    hard_own = hard_negatives(cls_loss.detach().numpy(), gt, half)
+    hard = hard_own if hard_neg is None else np.asarray(hard_neg).reshape(N, half)
     rand_neg = np.asarray(rand_neg).reshape(N, half)
     neg_idx = np.concatenate([hard, rand_neg], axis=1)
     mask = gt.copy()
@@ -293,7 +299,7 @@ def loss_step(kind, outs, bbox, vertices=None, labels=None, rand_neg=None, lm_ra
     mask_gray_zone_cls(mask, bbox, lab)
     m = T(mask)
     res = {'gt': gt, 'loc_gt': loc_gt, 'pos': pos, 'half': half, 'neg_idx': neg_idx,
-           'mask_sel': mask_sel, 'mask': mask}
+           'mask_sel': mask_sel, 'mask': mask, 'hard_own': hard_own}
 
     if kind == 'DenseBox':
         # :2914-2918  (lambda_loc multiplies inside the sum there)
@@ -306,19 +312,22 @@ def loss_step(kind, outs, bbox, vertices=None, labels=None, rand_neg=None, lm_ra
     lm_loss = (lm - heat_t) ** 2
     rf_loss = (rf - gt_t) ** 2
     lm_mask = heat_gt.copy()
-    lm_neg_all = []
+    lm_neg_all, lm_hard_own = [], []
     for i in range(4):
         gti = heat_gt[:, i:i + 1]
         li = lm_loss[:, i:i + 1].detach().numpy()
         posi = nonzero4(gti)
         hardi = hard_negatives(li, gti, 1)
+        lm_hard_own.append(hardi)
+        if lm_hard_neg is not None:
+            hardi = np.asarray(lm_hard_neg)[i].reshape(N, 1)
         negi = np.concatenate([hardi, np.asarray(lm_rand_neg)[i].reshape(N, 1)], axis=1)
         lm_neg_all.append(negi)
         view = lm_mask[:, i:i + 1]              # numpy basic slice = view, like the torch view at :2119
         mask_by_sel(view, posi, negi)
         mask_gray_zone_lm(view, posi)
     ml = T(lm_mask)
-    res.update({'heat_gt': heat_gt, 'lm_mask': lm_mask, 'lm_neg_idx': np.stack(lm_neg_all)})
+    res.update({'heat_gt': heat_gt, 'lm_mask': lm_mask, 'lm_neg_idx': np.stack(lm_neg_all), 'lm_hard_own': np.stack(lm_hard_own)})
 
     det = lambda_det * (torch.sum(m * cls_loss) + lambda_loc * torch.sum(m * gt_t * loc_loss))
     if kind == 'DenseBoxLM':

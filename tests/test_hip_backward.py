@@ -123,27 +123,168 @@ def test_sgd_kernel_exact_against_captured_grads(golden):
             assert np.allclose(p.detach().cpu().numpy(), ref, rtol=1e-6, atol=1e-9), (n_, step)
 
 
-@pytest.mark.parametrize('dtype,cos_min', [('bf16', 0.97), ('f16', 0.995)])
-def test_training_step_low_precision(golden, dtype, cos_min):
-    """bf16/f16 compute with fp32 accumulation: gradients stay aligned with the fp32 reference gradients."""
+def _oracle_step(kind, P, x, g, sl, step, masks=None, hard=None, lm_hard=None):
+    """The CPU oracle's training step (test infrastructure; pinned to the reference by tests/test_oracle_golden.py) on the fixture's patches
+    with the fixture's random negatives: (loss, {param: gradient}, loss_step's result dict)."""
+    from oracle import densebox_oracle as O
+    p = 's%d_' % step
+    neg0 = g[p + 'neg_idx_0']
+    half = neg0.shape[1] // 2
+    lm_rand = None if kind == 'DenseBox' else np.stack([g[p + 'neg_idx_%d' % (1 + j)][:, 1:] for j in range(4)])
+    kw = {k[3:]: float(g[k]) for k in g.files if k.startswith('kw_')}
+    for v in P.values():
+        v.grad = None
+    outs = O.forward(kind, P, x[sl], dropout_masks=masks)
+    res = O.loss_step(kind, outs, g['bbox'][sl], g['vert'][sl], g['lab'][sl], rand_neg=neg0[:, half:], lm_rand_neg=lm_rand,
+                      hard_neg=hard, lm_hard_neg=lm_hard, **kw)
+    res['loss'].backward()
+    return float(res['loss'].detach()), {k: v.grad.numpy().copy() for k, v in P.items() if v.grad is not None}, res
+
+
+def _cpu_params(net):
+    return {k: v.detach().cpu().clone().requires_grad_(True) for k, v in net.named_parameters()}
+
+
+def _hash_masks(eng, kind):
+    """The keep masks the forward's counter-based hash drew, read back from the hidden map (a dropped element is exactly 0)."""
+    from densebox_amd.engine import _HEADS
+    keep = (eng.read_activation('hid') != 0)
+    frac = keep.float().mean().item()
+    assert 0.49 < frac < 0.51, frac
+    return {h: keep[:, 512 * i:512 * (i + 1)].float().cpu() for i, (h, _) in enumerate(_HEADS[kind])}
+
+
+# Per-tensor bars of the 16-bit training step against the fp32 reference step: relative L2 error of every parameter gradient and
+# | ||g|| / ||g_ref|| - 1 | (a scale error, or a wrong tenth of one gradient, fails both; a cosine of 0.995 -- round 5's check -- passes them).
+# The error grows with the depth of the backward chain (every gradient map is rounded to 16 bits, ReLU gates and 2x2 arg-maxes of near-ties
+# flip), so the bars are per layer group: measured on this fixture (profiles/r06_grad_errors.txt) + ~30 %.  (rel-L2 f16, bf16), prefix match.
+LOWP_BARS = [(('conv5_', 'conv6_'), 6e-3, 3e-2), (('conv4_',), 1.3e-2, 5e-2), (('conv3_', 'conv2_2'), 1.8e-2, 5.5e-2),
+             (('conv2_1',), 2.1e-2, 6e-2), (('conv1_2',), 3.6e-2, 1.1e-1), (('conv1_1',), 6.5e-2, 2.5e-1)]
+LOWP_NORM = {'f16': 3e-3, 'bf16': 3.5e-2}
+
+
+def _lowp_bar(name, dtype):
+    for pre, f16, bf16 in LOWP_BARS:
+        if name.startswith(pre):
+            return f16 if dtype == 'f16' else bf16
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize('dropout', ['hash', 'off'])
+@pytest.mark.parametrize('dtype', ['f16', 'bf16'])
+def test_training_step_16bit_default_path_vs_oracle_per_tensor(golden, dtype, dropout):
+    """The step bench.py times -- 16-bit, heads backward by linearity (lin_bwd), hidden gradient generated in its consumers (heads_gen),
+    hash dropout -- against the fp32 oracle on the same patches, the same random negatives and the SAME dropout mask (exported from the
+    hidden map): every gradient within LOWP_BARS.  'off': Dropout disabled, the reference-captured gradients themselves are the bar's
+    reference.  The hard negatives are the 16-bit step's own selection (its top-k over its own losses; the rule is pinned bit-exactly in
+    test_hip_loss.py) -- at most a few of them differ from the fp32 selection, asserted here."""
     g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', dtype)
-    outs, loss = _step(g, kind, net, n, x, 0)
-    assert np.isclose(float(loss.detach()), float(g['s0_loss']), rtol=5e-2)
+    P = _cpu_params(net)
+    if dropout == 'hash':
+        for m in net.modules():
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.5
+        net.dropout_masks = None
+    sl = slice(0, n)
+    outs = net(x[sl].cuda())
+    neg0 = g['s0_neg_idx_0']
+    half = neg0.shape[1] // 2
+    lm_rand = np.stack([g['s0_neg_idx_%d' % (1 + j)][:, 1:] for j in range(4)])
+    kw = {k[3:]: float(g[k]) for k in g.files if k.startswith('kw_')}
+    loss, dbg = net.loss(outs, g['bbox'][sl], g['vert'][sl], g['lab'][sl], rand_neg_indices=neg0[:, half:], lm_rand_neg_indices=lm_rand,
+                         return_debug=True, **kw)
     loss.backward()
-    worst = 1.0
+    eng = net.engine()
+    Pl = eng.last_plan
+    assert Pl.heads_gen and 'd_hid' not in Pl.B and 'd_ups' not in Pl.B and Pl.drop_hash == (dropout == 'hash')
+    masks = _hash_masks(eng, kind) if dropout == 'hash' else None
+    hard = dbg['neg_idx'][:, :half].cpu().numpy()
+    lm_hard = dbg['lm_neg_idx'][:, :, :1].cpu().numpy()
+    lo, go, res = _oracle_step(kind, P, x, g, sl, 0, masks=masks, hard=hard, lm_hard=lm_hard)
+    # the 16-bit selection against the oracle's own: same set up to near-ties
+    differ = sum(len(set(a) ^ set(b)) // 2 for a, b in zip(hard.tolist(), res['hard_own'].tolist()))
+    assert differ <= max(2, hard.size // 20), (differ, hard.size)
+    assert abs(float(loss.detach()) - lo) <= (2e-3 if dtype == 'f16' else 1.5e-2) * abs(lo), (float(loss.detach()), lo)
+    bar_norm = LOWP_NORM[dtype]
+    worst, bad = (0.0, 0.0), []
     for name, prm in net.named_parameters():
-        key = 's0_g_' + name
-        if key not in g.files:
+        if name not in go:
+            assert prm.grad is None, name
             continue
-        ref = g[key].reshape(-1).astype(np.float64)
+        ref = go[name].reshape(-1).astype(np.float64)
         got = prm.grad.detach().float().cpu().numpy().reshape(-1).astype(np.float64)
         assert np.isfinite(got).all(), name
-        if np.abs(ref).max() == 0:
+        nr = np.linalg.norm(ref)
+        if nr == 0:
+            assert np.linalg.norm(got) == 0, name
             continue
-        cos = float(ref @ got / (np.linalg.norm(ref) * np.linalg.norm(got) + 1e-300))
-        worst = min(worst, cos)
-        assert cos >= cos_min, (name, cos)
-    print('worst cosine', dtype, worst)
+        rel = np.linalg.norm(got - ref) / nr
+        ratio = abs(np.linalg.norm(got) / nr - 1.0)
+        worst = (max(worst[0], rel), max(worst[1], ratio))
+        if os.environ.get('DBX_PRINT_GRAD_ERR') == '1':
+            print('\n%-5s %-5s %-24s rel_l2 %.3e  norm-1 %.3e' % (dtype, dropout, name, rel, ratio), end='')
+        if not (rel <= _lowp_bar(name, dtype) and ratio <= bar_norm):
+            bad.append((name, rel, ratio))
+    assert not bad, bad
+    if dropout == 'off':
+        # ... and against the reference-captured gradients themselves (the oracle is pinned to them at 1e-6; this closes the loop on the GPU box)
+        for name, prm in net.named_parameters():
+            key = 's0_g_' + name
+            if key in g.files and np.abs(g[key]).max() > 0:
+                ref = g[key].reshape(-1).astype(np.float64)
+                got = prm.grad.detach().float().cpu().numpy().reshape(-1).astype(np.float64)
+                assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= 1.2 * _lowp_bar(name, dtype), name
+    print('worst rel-L2 / norm ratio', dtype, dropout, worst)
+
+
+@pytest.mark.parametrize('name', ['train_DenseBox', 'train_DenseBox_dropout', 'train_DenseBoxLM', 'train_DenseBoxLMLOC'])
+def test_training_step_f32_with_the_16bit_backward_structure_vs_reference(golden, name, monkeypatch):
+    """DBX_F32_LIN=1: the exact-fp32 kernels run the backward STRUCTURE of the benchmarked 16-bit step -- conv4_4's part of the heads' first
+    convs on conv4_4's own grid after one transposed up-sampling of the hidden gradient (dbx_head2_backward_up, wgrad column slices, the two
+    data-gradient parts) and, without an injected mask, the hidden gradient GENERATED inside its two 60x60 consumers (the fp32 reference
+    instantiations of dbx_heads1_wgrad_gen / dbx_heads1_dgrad_gen; the stored d_hid is poisoned with NaN behind its producer) -- against
+    the gradients captured from the reference's own training loop at the plain fp32 path's tolerance.  Pins the algebra and the plumbing
+    (slices, scale, seeds, W2 pointers, per-head k) of what bench.py times to the reference."""
+    monkeypatch.setenv('DBX_F32_LIN', '1')
+    g, kind, net, n, x = _setup(golden, name, 'f32')
+    outs, loss = _step(g, kind, net, n, x, 0)
+    assert np.isclose(float(loss.detach()), float(g['s0_loss']), rtol=1e-4)
+    loss.backward()
+    Pl = net.engine().last_plan
+    assert Pl.flags[0] and Pl.flags[4] and 'd_ups' not in Pl.B and Pl.heads_gen
+    if str(g['dropout']) != 'mask':
+        bh = Pl.B['d_hid']
+        assert bool(torch.isnan(Pl.ws[bh.off:bh.off + 4096].view(torch.float32)).all())      # generated, not read: the buffer is poison
+    _check_grads(g, net, 0)
+
+
+def test_training_step_f32_generated_structure_with_hash_dropout_vs_oracle(golden, monkeypatch):
+    """The same structure with the forward's hash dropout on (the seed / scale / keep-bit plumbing of the generators): fp32 kernels against
+    the oracle fed the exported mask, element-wise at fp32 tolerance."""
+    monkeypatch.setenv('DBX_F32_LIN', '1')
+    g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', 'f32')
+    P = _cpu_params(net)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.5
+    net.dropout_masks = None
+    outs, loss = _step(g, kind, net, n, x, 0)
+    loss.backward()
+    eng = net.engine()
+    assert eng.last_plan.drop_hash and eng.last_plan.heads_gen
+    lo, go, _ = _oracle_step(kind, P, x, g, slice(0, n), 0, masks=_hash_masks(eng, kind))
+    assert abs(float(loss.detach()) - lo) <= 1e-4 * abs(lo)
+    for name, prm in net.named_parameters():
+        if name not in go:
+            assert prm.grad is None, name
+            continue
+        ref, got = go[name].reshape(-1).astype(np.float64), prm.grad.detach().float().cpu().numpy().reshape(-1).astype(np.float64)
+        rel_l2 = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300)
+        rel_max = np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-300)
+        if name.startswith(('conv1_', 'conv2_', 'conv3_')):          # below a max-pool: see _check_grads
+            assert rel_l2 <= 5e-3 and rel_max <= 3e-2, (name, rel_l2, rel_max)
+        else:
+            assert rel_max <= 2e-4, (name, rel_max)
 
 
 def test_dataparallel_world1_equals_plain_autograd(golden):

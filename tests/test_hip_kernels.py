@@ -1257,3 +1257,53 @@ def test_heads1_dgrad_gen_equals_the_gated_gemm_on_the_materialised_hidden_gradi
     assert float((a - b).abs().max()) <= tol, (float((a - b).abs().max()), float(a.abs().max()))
     assert float(ty2[:, 0].float().abs().sum()) == 0 and float(ty2[:, :, 0].float().abs().sum()) == 0      # halo rows / columns untouched
     assert torch.equal((b == 0), (a == 0)) or float(((b == 0) != (a == 0)).float().mean()) < 1e-3           # same gate pattern
+
+
+@pytest.mark.parametrize('dtn', ['f16', 'bf16'])
+@pytest.mark.parametrize('drop', ['hash', 'none'])
+def test_heads_gen_16bit_kernels_equal_their_fp32_reference_forms_exactly(drop, dtn):
+    """The MFMA generators of the 16-bit step (wgrad_wide2_kernel<T, true>, heads1_dgrad_gen_kernel<T>) against the one-thread-per-output fp32
+    instantiations the parity suite runs against the reference (csrc/heads_ref_f32.hip) on operands whose every product and partial sum is
+    exactly representable (small integers and halves): dW1 / db1 BITWISE equal, d_x equal to the fp32 result rounded once to the 16-bit type.
+    Ties the kernels bench.py times to the ones test_training_step_f32_with_the_16bit_backward_structure_vs_reference pins to the reference."""
+    L = _lib.lib()
+    dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
+    n, h, w, ks = 3, 60, 60, [1, 4, 4, 8]
+    nh = len(ks)
+    g = torch.Generator(device='cpu').manual_seed(77)
+
+    def ri(shape, lo, hi, scale=1.0):
+        return torch.randint(lo, hi + 1, shape, generator=g).float() * scale
+    dout = torch.zeros(n, 8 * nh, h, w)
+    for i, k in enumerate(ks):
+        dout[:, 8 * i:8 * i + k] = ri((n, k, h, w), -2, 2)
+    w2 = [ri((k, 512), -2, 2, 0.5).cuda().contiguous() for k in ks]
+    w1 = [ri((512, 768, 1, 1), -2, 2, 0.5).cuda().contiguous() for _ in ks]
+    x = ri((n, 256, h, w), -3, 3)
+    gate = ri((n, 256, h, w), -1, 1)
+    use_hash, seed = (1, 0xACE1) if drop == 'hash' else (0, 0)
+    karr = (C.c_int32 * nh)(*ks)
+    wp = (C.c_void_p * nh)(*[t.data_ptr() for t in w2])
+    res = {}
+    for name, d_, td_ in (('lo', dt, tdt), ('f32', _lib.F32, torch.float32)):
+        fo, to, dv = framed(dout, 0, td_)
+        fx, tx, xv = framed(x, 1, td_)
+        fg, tg, gv = framed(gate, 1, td_)
+        fy, ty, yv = framed(torch.zeros(n, 256, h, w), 1, td_)
+        dz = View(None, n, h, w, 1, 512 * nh, 0, 512 * nh)
+        sc = torch.empty(max(1024, L.dbx_conv_wgrad_scratch_bytes(d_, C.byref(dz), C.byref(xv), 1, 1)), dtype=torch.uint8, device='cuda')
+        dw = torch.full((512 * nh, 300, 1, 1), 7.0, device='cuda'); db = torch.full((512 * nh,), 7.0, device='cuda')
+        check(L.dbx_heads1_wgrad_gen(d_, C.byref(dv), C.byref(xv), wp, karr, nh, use_hash, seed, 256, ptr(dw), 300, 44, ptr(db), ptr(sc), stream_ptr()))
+        dd = ConvDesc(d_, 1, 1, 0, 512 * nh, 256, 0)
+        wimg = torch.zeros(L.dbx_conv_packed_elems(C.byref(dd)) * _lib.ESIZE[d_], dtype=torch.uint8, device='cuda')
+        for i, wt in enumerate(w1):
+            check(L.dbx_pack_weight(d_, 5 if name == 'lo' else 1, ptr(wt), 512, 768, 1, 1, ptr(wimg), 256, 512 * nh, -512, 512 * i, stream_ptr()))
+        check(L.dbx_heads1_dgrad_gen(d_, C.byref(dv), wp, karr, nh, use_hash, seed, ptr(wimg), C.byref(yv), C.byref(gv), stream_ptr()))
+        torch.cuda.synchronize()
+        res[name] = (dw.clone(), db.clone(), ty.clone())
+    (dwa, dba, ya), (dwb, dbb, yb) = res['lo'], res['f32']
+    assert float(dwb[:, 44:300].abs().sum()) > 0 and float(dbb.abs().sum()) > 0 and float(yb.abs().sum()) > 0
+    assert torch.equal(dwa, dwb) and torch.equal(dba, dbb)
+    assert torch.equal(ya.float(), yb.to(tdt).float())
+    if drop == 'hash':          # about half of the hidden gradient is dropped: the two runs must differ from the no-dropout ones
+        assert 0.2 < float((yb != 0).float().mean()) < 0.6
