@@ -348,11 +348,15 @@ def run(args):
         # (DenseBox.py:2070-2074; host loop over the boxes + one int64 all-reduce on the gloo side group) and the host RNG
         # draws (DenseBox.py:2089-2094, :2133-2138)
         nonlocal half
-        p_global = dp.global_positive_num(bbox, use_lab)
+        p_global = dp.global_positive_num(bbox, use_lab)       # (consumes the count prefetched behind the previous step's launches)
         _, half = LB.neg_counts(p_global, n * world)
         rn = np.stack([rs.choice(3600, half, replace=False) for _ in range(n)]) if half else np.zeros((n, 0), np.int64)
         lrn = rs.randint(0, 3600, size=(4, n, 1)) if kind != 'DenseBox' else None
-        return dp.step(x, bbox, vert, lab, rand_neg_indices=rn, lm_rand_neg_indices=lrn, positive_num_global=p_global)
+        out = dp.step(x, bbox, vert, lab, rand_neg_indices=rn, lm_rand_neg_indices=lrn, positive_num_global=p_global)
+        # the NEXT step's positive count depends on its labels only: its int64 all-reduce (gloo side group) flies while this step's
+        # kernels drain instead of standing in front of the next forward's first launch
+        dp.prefetch_positive_num(bbox, use_lab)
+        return out
 
     def barrier():
         if world > 1:
@@ -438,7 +442,8 @@ def run(args):
                                    'all-reduce + SGD) of %s on 240x240 patches' % kind,
                        'net': kind, 'batch_per_gpu': n, 'global_batch': n * world, 'patch': '240x240',
                        'parallelism': 'dp%d' % world, 'half_neg': half, 'loss': round(loss_val, 2),
-                       'grad_finite': True, 'grad_absmax': round(grad_absmax, 3)},
+                       'grad_finite': True, 'grad_absmax': round(grad_absmax, 3),
+                       'f16_overflow_guard': {'on': bool(dp.guard_f16 and args.dtype == 'f16'), 'skipped_steps': dp.skipped_steps()}},
             'step_tflops_per_gpu': round(n * STEP_GFLOP[kind] / (ms * 1e-3) / 1e3, 1),
             'roofline': roof,
             # the live process group the gradient all-reduce ran on ("nccl" is RCCL on ROCm): lets a scaling run be checked for
@@ -471,6 +476,7 @@ def run(args):
             out['inference'] = inference(kind, dev)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(kind, args.cpu_seconds)
+    dp.drain_prefetch()
     barrier()
     if rank == 0:
         print(json.dumps(out))

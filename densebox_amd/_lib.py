@@ -125,12 +125,15 @@ SIGNATURES = {
     'dbx_mask_gray_zone_cls': (C.c_int, [_VP, _VP, _VP, _I32, _VP]),
     'dbx_mask_gray_zone_lm': (C.c_int, [_VP, _I32, _VP, _I64, _VP]),
     'dbx_sgd_step': (C.c_int, [_VP, _VP, _I32, _I64, _F, _F, _F, _I32, _VP]),
+    'dbx_grad_guard': (C.c_int, [_VP, _I64, _VP, _I32, _VP]),
+    'dbx_sgd_step_guarded': (C.c_int, [_VP, _VP, _I32, _I64, _F, _F, _F, _I32, _VP, _I32, _VP]),
+    'dbx_sgd_pack_step_guarded': (C.c_int, [_I32, _VP, _I32, _I64, _VP, _F, _F, _F, _I32, _VP, _I32, _VP]),
     'dbx_detect_scratch_bytes': (_I64, [_I32, _I32, _I32]),
     'dbx_detect': (C.c_int, [_VP, _VP, _VP, _VP, _I32, _I32, _I32, _D, _VP, _I32, _VP, _VP, _VP, _VP]),
     'dbx_nms': (C.c_int, [_VP, _I32, _I32, _D, _VP, _VP, _VP]),
 }
 
-ABI_VERSION = 6          # include/densebox_hip.h DBX_ABI_VERSION this binding was written against
+ABI_VERSION = 7          # include/densebox_hip.h DBX_ABI_VERSION this binding was written against
 _lib = None
 MISSING = []
 

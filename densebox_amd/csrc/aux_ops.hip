@@ -1665,7 +1665,11 @@ __device__ __forceinline__ void pack_scatter_elem(const PackDst& d, int o, int c
 }
 template <typename T>
 __global__ __launch_bounds__(256) void sgd_pack_kernel(const SgdPackJob* __restrict__ jobs, float* const* __restrict__ ptrs, float lr, float mu,
-                                                       float wd, int first) {
+                                                       float wd, int first, int* __restrict__ guard, int step_id) {
+    if (guard && guard[0] == step_id) {                                 // (dbx_grad_guard found a non-finite gradient: nothing changes, the packed images stay valid)
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(guard + 1, 1);
+        return;
+    }
     const SgdPackJob& j = jobs[blockIdx.y];
     float* p = j.p;
     const int pidx = j.pidx, taps = j.taps, ci = j.ci, co = j.co, ndst = j.ndst;
@@ -1755,18 +1759,23 @@ __global__ __launch_bounds__(256) void sgd_pack_kernel(const SgdPackJob* __restr
     }
 }
 template <typename T> static int sgd_pack_t(const void* jobs, int count, long long max_elems, float* const* ptrs, float lr, float mu, float wd,
-                                            int first, hipStream_t s) {
+                                            int first, int* guard, int step_id, hipStream_t s) {
     int bx = (int)((max_elems + 255) / 256);
     bx = bx < 1 ? 1 : (bx > 256 ? 256 : bx);
-    hipLaunchKernelGGL(sgd_pack_kernel<T>, dim3(bx, count), dim3(256), 0, s, (const SgdPackJob*)jobs, ptrs, lr, mu, wd, first);
+    hipLaunchKernelGGL(sgd_pack_kernel<T>, dim3(bx, count), dim3(256), 0, s, (const SgdPackJob*)jobs, ptrs, lr, mu, wd, first, guard, step_id);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }
-extern "C" int dbx_sgd_pack_step(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, float* const* ptrs, float lr, float momentum,
-                                 float weight_decay, int32_t first_step, void* stream) {
+extern "C" int dbx_sgd_pack_step_guarded(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, float* const* ptrs, float lr,
+                                         float momentum, float weight_decay, int32_t first_step, int32_t* guard, int32_t step_id, void* stream) {
     DBX_REQUIRE(jobs && count > 0, "sgd_pack: empty job table");
     static_assert(sizeof(PackDst) == 40 && sizeof(SgdPackJob) == 192, "job record layout (include/densebox_hip.h)");
-    DBX_DISPATCH_DTYPE(dtype, sgd_pack_t, jobs, count, (long long)max_elems, ptrs, lr, momentum, weight_decay, first_step, (hipStream_t)stream);
+    DBX_DISPATCH_DTYPE(dtype, sgd_pack_t, jobs, count, (long long)max_elems, ptrs, lr, momentum, weight_decay, first_step, guard, step_id,
+                       (hipStream_t)stream);
+}
+extern "C" int dbx_sgd_pack_step(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, float* const* ptrs, float lr, float momentum,
+                                 float weight_decay, int32_t first_step, void* stream) {
+    return dbx_sgd_pack_step_guarded(dtype, jobs, count, max_elems, ptrs, lr, momentum, weight_decay, first_step, nullptr, 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- eval-mode head folding

@@ -889,14 +889,22 @@ __global__ __launch_bounds__(512) void wgrad_all9s_kernel(const WgradArgs a) {
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
     };
     // dz fragments of K half kk (stage byte offset sb is added to the bases once per step)
-    auto rdA4 = [&](u32x4 (&af)[4], unsigned sb, auto KK_) {
+    // (the halves stay the asm's own output registers until the hand-written lgkmcnt(0) has retired the reads -- wait_a4 below takes them
+    //  as in/out operands, so no register move or spill of theirs can be scheduled in front of it: the compiler's waitcnt pass does not
+    //  see LDS reads issued from inline asm -- and only then become the MFMA operands)
+    struct RawA4 { u32x2 lo[4], hi[4]; };
+    auto rdA4 = [&](RawA4& ra, unsigned sb, auto KK_) {
         constexpr int kk = decltype(KK_)::value;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            u32x2 lo, hi;
-            tr(lo, aA[mi] + sb, pipe::IC<kk * 8192>{}); tr(hi, aA[mi] + sb, pipe::IC<kk * 8192 + 1024>{});
-            af[mi] = (u32x4){lo.x, lo.y, hi.x, hi.y};
-        }
+        for (int mi = 0; mi < 4; ++mi) { tr(ra.lo[mi], aA[mi] + sb, pipe::IC<kk * 8192>{}); tr(ra.hi[mi], aA[mi] + sb, pipe::IC<kk * 8192 + 1024>{}); }
+    };
+    auto wait_a4 = [](RawA4& ra) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ra.lo[0]), "+v"(ra.lo[1]), "+v"(ra.lo[2]), "+v"(ra.lo[3]), "+v"(ra.hi[0]), "+v"(ra.hi[1]), "+v"(ra.hi[2]),
+                     "+v"(ra.hi[3]) :: "memory");
+    };
+    auto asmA4 = [](u32x4 (&af)[4], const RawA4& ra) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) af[mi] = (u32x4){ra.lo[mi].x, ra.lo[mi].y, ra.hi[mi].x, ra.hi[mi].y};
     };
     auto rdRunA = [&](Run& r, unsigned sb, auto KK_, auto KY_) {
         constexpr int kk = decltype(KK_)::value, ky = decltype(KY_)::value;
@@ -934,11 +942,13 @@ __global__ __launch_bounds__(512) void wgrad_all9s_kernel(const WgradArgs a) {
         // ---- phase A
         {
             Run r0, r1;
-            rdA4(af0, so, pipe::IC<0>{}); rdRunA(r0, so, pipe::IC<0>{}, pipe::IC<0>{}); rdRunA(r1, so, pipe::IC<0>{}, pipe::IC<1>{});
+            RawA4 ra;
+            rdA4(ra, so, pipe::IC<0>{}); rdRunA(r0, so, pipe::IC<0>{}, pipe::IC<0>{}); rdRunA(r1, so, pipe::IC<0>{}, pipe::IC<1>{});
             __builtin_amdgcn_sched_barrier(0);
             ALL9S_PART0(po);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_a4(ra);
             __builtin_amdgcn_sched_barrier(0);
+            asmA4(af0, ra);
             const Frag3 f0 = shuffle(r0), f1 = shuffle(r1);
             __builtin_amdgcn_sched_barrier(0);
             sbar();
@@ -950,11 +960,13 @@ __global__ __launch_bounds__(512) void wgrad_all9s_kernel(const WgradArgs a) {
         // ---- phase B
         {
             Run r0, r1;
-            rdA4(af1, so, pipe::IC<1>{}); rdRunA(r0, so, pipe::IC<0>{}, pipe::IC<2>{}); rdRunA(r1, so, pipe::IC<1>{}, pipe::IC<0>{});
+            RawA4 ra;
+            rdA4(ra, so, pipe::IC<1>{}); rdRunA(r0, so, pipe::IC<0>{}, pipe::IC<2>{}); rdRunA(r1, so, pipe::IC<1>{}, pipe::IC<0>{});
             __builtin_amdgcn_sched_barrier(0);
             ALL9S_PART1(po);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            wait_a4(ra);
             __builtin_amdgcn_sched_barrier(0);
+            asmA4(af1, ra);
             const Frag3 f0 = shuffle(r0), f1 = shuffle(r1);
             __builtin_amdgcn_sched_barrier(0);
             sbar();

@@ -6,8 +6,16 @@
 
 // ---------------------------------------------------------------------------------------------- SGD (DenseBox.py:2001-2004)
 // torch.optim.SGD, dampening 0, no Nesterov: g = grad + wd*p; buf = g (first step) | mu*buf + g; p -= lr*buf
+// guard (round 6): dbx_grad_guard leaves step_id in guard[0] when any gradient element of the step is not finite (f16 training keeps its
+// activation gradients in 16-bit frames and the reference loss is an un-normalised sum: an overflow there reaches every weight gradient
+// behind it as inf / NaN); an update launched with that guard and the same step_id then returns without touching anything and counts
+// the skipped step in guard[1].  guard == NULL: the plain update.
 __global__ void sgd_kernel(float* const* __restrict__ ptrs, const long long* __restrict__ sizes, float lr, float mu, float wd,
-                           int first) {
+                           int first, int* __restrict__ guard, int step_id) {
+    if (guard && guard[0] == step_id) {
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(guard + 1, 1);
+        return;
+    }
     const int t = blockIdx.y;
     float* p = ptrs[3 * t];
     const float* g = ptrs[3 * t + 1];
@@ -17,13 +25,40 @@ __global__ void sgd_kernel(float* const* __restrict__ ptrs, const long long* __r
         p[i] = dbx_sgd_update(p[i], g[i], b + i, lr, mu, wd, first);
     }
 }
-extern "C" int dbx_sgd_step(float* const* ptrs, const int64_t* sizes, int32_t count, int64_t max_size, float lr, float momentum,
-                            float weight_decay, int32_t first_step, void* stream) {
+extern "C" int dbx_sgd_step_guarded(float* const* ptrs, const int64_t* sizes, int32_t count, int64_t max_size, float lr, float momentum,
+                                    float weight_decay, int32_t first_step, int32_t* guard, int32_t step_id, void* stream) {
     DBX_REQUIRE(ptrs && sizes && count > 0, "sgd: empty parameter list");
     int bx = (int)((max_size + 255) / 256);
     bx = bx < 1 ? 1 : (bx > 512 ? 512 : bx);
     hipLaunchKernelGGL(sgd_kernel, dim3(bx, count), dim3(256), 0, (hipStream_t)stream, ptrs, (const long long*)sizes, lr, momentum,
-                       weight_decay, first_step);
+                       weight_decay, first_step, guard, step_id);
+    DBX_LAUNCH_CHECK();
+    return DBX_OK;
+}
+extern "C" int dbx_sgd_step(float* const* ptrs, const int64_t* sizes, int32_t count, int64_t max_size, float lr, float momentum,
+                            float weight_decay, int32_t first_step, void* stream) {
+    return dbx_sgd_step_guarded(ptrs, sizes, count, max_size, lr, momentum, weight_decay, first_step, nullptr, 0, stream);
+}
+// one pass over the step's flat gradient buffer (46.7 MB for DenseBoxLMLOC: ~12 us): |x| with the exponent field all ones = inf or NaN
+__global__ __launch_bounds__(256) void grad_guard_kernel(const float* __restrict__ g, long long n, int* __restrict__ guard, int step_id) {
+    const long long n4 = n >> 2;
+    const u32x4* g4 = (const u32x4*)g;
+    unsigned bad = 0u;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const u32x4 v = g4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bad |= ((v[e] & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)(n & 3))
+        bad |= ((__float_as_uint(g[(n4 << 2) + threadIdx.x]) & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;
+    if (__any((int)bad) && (threadIdx.x & 63) == 0) atomicMax(guard, step_id);
+}
+extern "C" int dbx_grad_guard(const float* grads, int64_t n, int32_t* guard, int32_t step_id, void* stream) {
+    DBX_REQUIRE(grads && guard && n >= 0 && step_id > 0 && ((size_t)grads % 16) == 0, "grad_guard: 16-byte aligned gradients, a guard word pair, step ids from 1");
+    if (n == 0) return DBX_OK;
+    long long blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(grad_guard_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, grads, (long long)n, guard, step_id);
     DBX_LAUNCH_CHECK();
     return DBX_OK;
 }

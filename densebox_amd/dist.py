@@ -18,10 +18,18 @@ import torch
 import torch.distributed as dist
 
 
+def rendezvous_timeout_s():
+    """Bound on rendezvous and on the first (preflight) collective: DBX_DIST_RENDEZVOUS_S, default 120 s -- the torch default of ten
+    minutes turns a mis-configured first multi-GPU run into a silent hang."""
+    return float(os.environ.get('DBX_DIST_RENDEZVOUS_S', '120'))
+
+
 def dist_timeout_s():
-    """Bound on rendezvous and on every collective of the process group (DBX_DIST_TIMEOUT_S, default 120 s: the torch default of ten
-    minutes turns a mis-configured first multi-GPU run into a silent hang)."""
-    return float(os.environ.get('DBX_DIST_TIMEOUT_S', '120'))
+    """Bound on every steady-state collective of the process group AND of the gloo control group (DBX_DIST_TIMEOUT_S, default 1800 s =
+    torch's own default for gloo).  Deliberately much longer than the rendezvous bound: ranks legitimately drift apart by minutes when
+    one of them does rank-0-only work between steps (a checkpoint, an evaluation pass, bench.py's rank-0 inference and CPU-baseline legs);
+    a caller whose rank-0-only work can exceed it raises the variable or puts a barrier-free region around that work."""
+    return float(os.environ.get('DBX_DIST_TIMEOUT_S', '1800'))
 
 
 def rccl_info():
@@ -30,7 +38,7 @@ def rccl_info():
            if k.startswith(('NCCL_', 'RCCL_', 'HSA_ENABLE_IPC', 'MASTER_', 'DBX_DIST_')) or k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
     info = {'backend': dist.get_backend() if dist.is_initialized() else None,
             'world': dist.get_world_size() if dist.is_initialized() else int(os.environ.get('WORLD_SIZE', '1')),
-            'timeout_s': dist_timeout_s(), 'env': env,
+            'timeout_s': dist_timeout_s(), 'rendezvous_timeout_s': rendezvous_timeout_s(), 'env': env,
             'gpus_visible': torch.cuda.device_count() if torch.cuda.is_available() else 0}
     return info
 
@@ -65,7 +73,7 @@ def preflight(dev):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     world, rank = dist.get_world_size(), dist.get_rank()
-    with watchdog(dist_timeout_s(), 'first all-reduce (%s, world %d)' % (dist.get_backend(), world), rank):
+    with watchdog(rendezvous_timeout_s(), 'first all-reduce (%s, world %d)' % (dist.get_backend(), world), rank):
         t = torch.full((1024,), float(rank + 1), device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t)
         if t.is_cuda:
@@ -77,7 +85,7 @@ def preflight(dev):
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, local_rank).
-    Rendezvous and collectives are bounded by dist_timeout_s()."""
+    The rendezvous is bounded by rendezvous_timeout_s(), the group's collectives afterwards by dist_timeout_s()."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -89,7 +97,14 @@ def init_from_env(backend=None):
             backend = os.environ.get('DBX_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             torch.cuda.set_device(local % torch.cuda.device_count())
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timedelta(seconds=dist_timeout_s()))
+        # rendezvous under the SHORT bound (a rank that never shows up fails the job in two minutes); once every rank is in, the group's
+        # collectives get the long one (torch keeps ONE timeout per group for both; _set_pg_timeout is its own hook for changing it)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timedelta(seconds=rendezvous_timeout_s()))
+        try:
+            from torch.distributed.distributed_c10d import _set_pg_timeout
+            _set_pg_timeout(timedelta(seconds=dist_timeout_s()))
+        except Exception as e:                                   # (a torch without the hook: the short bound stays, and is reported)
+            print('densebox_amd.dist: collectives keep the rendezvous timeout of %.0f s (%s)' % (rendezvous_timeout_s(), e), file=sys.stderr)
     return rank, world, local
 
 
@@ -178,10 +193,14 @@ class DataParallel:
             for p in net.parameters():                       # replicate rank 0's weights
                 dist.broadcast(p.data, src=0)
             # tiny host-side control collectives (positive counts) go over gloo: no device sync on the data path
-            self.ctl = dist.new_group(backend='gloo') if dist.get_backend() != 'gloo' else dist.group.WORLD
+            self.ctl = dist.new_group(backend='gloo', timeout=timedelta(seconds=dist_timeout_s())) if dist.get_backend() != 'gloo' \
+                else dist.group.WORLD
         eng = net.engine()
         self.reducer = GradReducer(net.named_parameters(), eng.grad_order(), bucket_bytes, always_reduce=always_reduce)
         eng.grad_sink = self.reducer
+        self._pf = None            # a prefetched global positive count: (local count, tensor, work)
+        # f16 steps run under the optimizer's overflow guard (optim.SGD.enable_guard; DBX_F16_GUARD=0: off); other types keep the plain update
+        self.guard_f16 = os.environ.get('DBX_F16_GUARD', '1') != '0' and hasattr(optimizer, 'enable_guard')
 
     def close(self):
         """Detach from the network: its engine writes gradients to ordinary tensors again (plain autograd training)."""
@@ -189,14 +208,52 @@ class DataParallel:
         if eng.grad_sink is self.reducer:
             eng.grad_sink = None
 
+    def prefetch_positive_num(self, bbox, labels=None):
+        """Start the global positive count (DenseBox.py:2070-2074) of the NEXT step's batch: it depends on the labels only, so its int64
+        all-reduce on the gloo control group can fly while this step's kernels drain.  Call it right after step(); the next
+        global_positive_num() / step() consumes it.  EVERY rank must prefetch (or none): the pending collective is consumed
+        unconditionally, a batch other than the prefetched one raises."""
+        from . import labels as LB
+        if self._pf is not None:
+            self._consume_prefetch()                      # (never two in flight: the collective order stays the call order on every rank)
+        p = int(LB.positive_count(bbox, labels).sum())
+        if self.collective:
+            t = torch.tensor([p], dtype=torch.int64)
+            self._pf = (p, t, dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl, async_op=True))
+        else:
+            self._pf = (p, None, None)
+
+    def drain_prefetch(self):
+        """Wait for a pending prefetch and drop its result (end of a run: no collective may be left in flight at destroy time)."""
+        if self._pf is not None:
+            self._consume_prefetch()
+
+    def _consume_prefetch(self):
+        p, t, w = self._pf
+        self._pf = None
+        if w is not None:
+            w.wait()
+            return p, int(t.item())
+        return p, p
+
     def global_positive_num(self, bbox, labels=None):
         from . import labels as LB
         p = int(LB.positive_count(bbox, labels).sum())
+        if self._pf is not None:
+            local, total = self._consume_prefetch()
+            if local != p:
+                raise RuntimeError('prefetch_positive_num() was given another batch than this step (local positives %d != %d)' % (local, p))
+            return total
         if self.collective:
             t = torch.tensor([p], dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.ctl)
             p = int(t.item())
         return p
+
+    def skipped_steps(self):
+        """f16 steps the overflow guard skipped so far (optim.SGD.skipped_steps; synchronises: call it where the loss is read).  What to do
+        about a non-zero count is the caller's policy; the documented fallback is net.compute_dtype = 'bf16' (same MFMA rate, fp32's range)."""
+        return self.opt.skipped_steps() if hasattr(self.opt, 'skipped_steps') else 0
 
     def _stage(self, dev, items):
         """Host-side loss inputs (boxes, vertices, labels, mining draws; ~10 KB) -> device through ONE pinned buffer and one
@@ -252,6 +309,8 @@ class DataParallel:
             bbox, vertices, labels, rand_neg_indices, lm_rand_neg_indices = self._stage(
                 x.device, [(bbox, torch.float32), (vertices, torch.float32), (labels, torch.float32),
                            (rand_neg_indices, torch.int64), (lm_rand_neg_indices, torch.int64)])
+        if self.guard_f16:
+            self.opt.enable_guard(self.reducer.flat, on=net.resolved_dtype(True) == 'f16')
         self.opt.zero_grad(set_to_none=True)
         self.reducer.begin()
         net.engine().sample_offset = self.rank * x.size(0)     # ranks draw different dropout masks (engine._next_drop_seed)

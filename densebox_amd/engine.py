@@ -487,7 +487,7 @@ class Engine:
             self._last_prep = (dt, tkey, lay)
             register_params(self, params)
 
-    def sgd_pack_step(self, live, ptrs, lr, momentum, weight_decay, first):
+    def sgd_pack_step(self, live, ptrs, lr, momentum, weight_decay, first, guard=None, step_id=0):
         """optim.SGD.step() with this engine's re-packing folded in (dbx_sgd_pack_step): one job per parameter updates it and emits the packed
         images the last training plan uses, so the next forward finds its weights packed and launches nothing.  `live`: the parameters with
         gradients, in the order of `ptrs` ([param, grad, momentum] pointers on the device).  Returns False when the plain two-launch path
@@ -525,7 +525,7 @@ class Engine:
                 if src not in pidx:
                     continue                              # no gradient: unchanged, its packed copies stay valid
                 if len(js) > 4 or len({(j[2], j[3], j[4]) for j in js}) != 1:
-                    self._sgd_tables = {skey: False}
+                    self._sgd_tables[skey] = False
                     return False
                 co, ci, taps = js[0][2], js[0][3], js[0][4]
                 tiled = es == 2 and taps <= 25 and all(
@@ -546,8 +546,13 @@ class Engine:
                 for k, j in enumerate(js):
                     rec[i]['d'][k] = (j[1], j[6], j[5], j[7], j[8], j[9], j[10], 0)
             st = (torch.from_numpy(rec.view(np.uint8).copy()).to(params[0].device), len(recs), max(r[2] * r[3] * r[4] for r in recs))
-            self._sgd_tables = {skey: st}
-        check(self.L.dbx_sgd_pack_step(dt, ptr(st[0]), st[1], st[2], ptr(ptrs), lr, momentum, weight_decay, 1 if first else 0, stream_ptr()))
+            if len(self._sgd_tables) >= 8:                  # (a caller cycling through many live-parameter sets: keep the cache small)
+                self._sgd_tables.pop(next(iter(self._sgd_tables)))
+            self._sgd_tables[skey] = st
+        # (guard: optim.SGD's overflow guard -- a step whose gradients were not finite changes nothing, see dbx_grad_guard; the version counters
+        #  move either way: the host does not know, and the packed images are current in both cases)
+        check(self.L.dbx_sgd_pack_step_guarded(dt, ptr(st[0]), st[1], st[2], ptr(ptrs), lr, momentum, weight_decay, 1 if first else 0,
+                                               ptr(guard), step_id, stream_ptr()))
         torch.autograd.graph.increment_version(live)
         self._wsig = (dt, True, tuple((p._version, p.data_ptr()) for p in params), lay)
         return True

@@ -44,8 +44,10 @@ const char* dbx_last_error(void);
  *   4  (round 4) dbx_head2_backward_up takes a d_hid view with a NULL ptr ("do not store it"); heads-gen entry points added
  *   5  (round 4) dbx_sgd_pack_step and dbx_heads_forward_fused_heads added; nothing changed
  *   6  (round 5) dbx_conv_plan may name DBX_K_P8 (the 8-phase kernel: plain packed weights); dbx_heads_forward_fusable returns WHICH kernel
- *      takes the fused heads forward (1 = ws / fragment-order weights as before, 2 = 8-phase / plain weights + plain second-weight image) */
-#define DBX_ABI_VERSION 6
+ *      takes the fused heads forward (1 = ws / fragment-order weights as before, 2 = 8-phase / plain weights + plain second-weight image)
+ *   7  (round 6) additions only: dbx_grad_guard, dbx_sgd_step_guarded, dbx_sgd_pack_step_guarded (f16 overflow guard); the heads-gen
+ *      entry points accept DBX_F32 (reference instantiations for the parity suite) */
+#define DBX_ABI_VERSION 7
 int dbx_version(void);
 /* device sanity: returns gfx arch number (950) of `device`, or <0 */
 int dbx_device_arch(int device);
@@ -392,6 +394,18 @@ int dbx_mask_gray_zone_lm(float* mask, int32_t n, const int64_t* pos_idx, int64_
  */
 int dbx_sgd_step(float* const* ptrs, const int64_t* sizes, int32_t count, int64_t max_size,
                  float lr, float momentum, float weight_decay, int32_t first_step, void* stream);
+/* Overflow guard of 16-bit training (round 6; no reference counterpart: the reference trains in fp32, DenseBox.py:2186-2187).  The f16 step
+ * keeps dL/d(pre-activation) in f16 frames and the loss is an un-normalised sum (DenseBox.py:2917): a residual that overflows 65504 there
+ * reaches every weight gradient behind it as inf / NaN.  dbx_grad_guard scans the step's gradients (one flat fp32 buffer, 16-byte aligned)
+ * and leaves `step_id` (> 0, increasing from step to step) in guard[0] when any element is not finite; dbx_sgd_step_guarded /
+ * dbx_sgd_pack_step_guarded launched with the same guard and step_id then change NOTHING (parameters, momentum buffers and packed images
+ * stay as they were) and add 1 to guard[1], the count of skipped steps a caller reads back whenever it reads the loss.  guard: two
+ * int32 on the device, zero-initialised by the caller; NULL = the unguarded update.  No host synchronisation anywhere. */
+int dbx_grad_guard(const float* grads, int64_t n, int32_t* guard, int32_t step_id, void* stream);
+int dbx_sgd_step_guarded(float* const* ptrs, const int64_t* sizes, int32_t count, int64_t max_size, float lr, float momentum,
+                         float weight_decay, int32_t first_step, int32_t* guard, int32_t step_id, void* stream);
+int dbx_sgd_pack_step_guarded(int32_t dtype, const void* jobs, int32_t count, int64_t max_elems, float* const* ptrs, float lr, float momentum,
+                              float weight_decay, int32_t first_step, int32_t* guard, int32_t step_id, void* stream);
 
 /* ------------------------------------------------------------------ decode + NMS (DenseBox.py:3114-3443)
  * top-K of the score map, corner/landmark decode to float64 rows [K, 5|13], greedy NMS (keep ovr <= thresh).

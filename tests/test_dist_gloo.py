@@ -88,6 +88,36 @@ def test_global_positive_count_and_broadcast():
     _run(_count_case)
 
 
+def _prefetch_case(rank, world):
+    """The next step's positive count in flight while this step runs (it depends on the labels only): the prefetched collective is
+    consumed by the next global_positive_num(), two prefetches never overlap, a batch other than the prefetched one raises."""
+    n = 5
+    bbox, vert, lab = synth.synth_labels(2 * n * world, seed=6, neg_frac=0.3)
+    net = D.DenseBoxLMLOC(synth.vgg19_standin(seed=0))
+    from densebox_amd.optim import SGD
+    dp = DataParallel(net, SGD(net.parameters(), lr=1e-9))
+    a = slice(rank * n, (rank + 1) * n)
+    b = slice((world + rank) * n, (world + rank + 1) * n)
+    want_a = int(LB.positive_count(bbox[:world * n], lab[:world * n]).sum())
+    want_b = int(LB.positive_count(bbox[world * n:], lab[world * n:]).sum())
+    dp.prefetch_positive_num(bbox[a], lab[a])
+    assert dp._pf is not None
+    assert dp.global_positive_num(bbox[a], lab[a]) == want_a and dp._pf is None
+    dp.prefetch_positive_num(bbox[a], lab[a])
+    dp.prefetch_positive_num(bbox[b], lab[b])                      # (the first one is drained, never two in flight)
+    assert dp.global_positive_num(bbox[b], lab[b]) == want_b
+    assert dp.global_positive_num(bbox[a], lab[a]) == want_a       # nothing pending: the blocking path
+    dp.prefetch_positive_num(bbox[a], lab[a])
+    assert int(LB.positive_count(bbox[a], lab[a]).sum()) > 0
+    with pytest.raises(RuntimeError):                              # twice the rows = twice the local positives: not the prefetched batch
+        dp.global_positive_num(torch.cat([bbox[a], bbox[a]]), torch.cat([lab[a], lab[a]]))
+    dist.barrier()
+
+
+def test_prefetched_positive_count():
+    _run(_prefetch_case)
+
+
 # ----------------------------------------------------------------------------------------------- sharded loss == global loss
 def _loss_case(rank, world):
     kind, n = 'DenseBoxLMLOC', 3

@@ -551,3 +551,52 @@ def test_sgd_with_repacking_folded_in_equals_update_then_pack(golden, name, dtyp
     p0 = next(net.parameters())
     assert not [k for k in vars(p0) if 'dbx' in k]
     assert torch.equal(pickle.loads(pickle.dumps(p0)).cpu(), p0.detach().cpu()) and torch.equal(copy.deepcopy(p0), p0)
+
+
+def test_f16_overflow_guard_skips_the_step_and_counts_it(golden, monkeypatch):
+    """f16 keeps dL/d(pre-activation) in 16-bit frames and the loss is an un-normalised sum (DenseBox.py:2917).  A step whose residuals
+    overflow them (here: lambda_det = 1e9 pushes dL/d(score) past 65504) produces non-finite weight gradients; under the guard
+    (dbx_grad_guard + dbx_sgd_pack_step_guarded, on by default for f16 steps of dist.DataParallel) it changes NOTHING -- parameters, momentum
+    buffers, packed weights -- and is counted on the device; the next, sane step updates as usual and equals the same step taken from the same
+    state without the bad one in between.  bf16 / fp32 steps run the plain update (fp32's range)."""
+    from densebox_amd.dist import DataParallel
+
+    def fresh():
+        g, kind, net, n, x = _setup(golden, 'train_DenseBoxLMLOC', 'f16')
+        opt = SGD(net.parameters(), lr=1e-8, momentum=0.9, weight_decay=5e-8)
+        return g, kind, net, n, x, opt, DataParallel(net, opt)
+
+    def dp_step(dp, g, n, x, **kw):
+        neg0 = g['s0_neg_idx_0']
+        half = neg0.shape[1] // 2
+        lm_rand = np.stack([g['s0_neg_idx_%d' % (1 + j)][:, 1:] for j in range(4)])
+        return dp.step(x[:n].cuda(), g['bbox'][:n], g['vert'][:n], g['lab'][:n], rand_neg_indices=neg0[:, half:], lm_rand_neg_indices=lm_rand, **kw)
+
+    g, kind, net, n, x, opt, dp = fresh()
+    assert dp.guard_f16
+    before = {k: p.detach().clone() for k, p in net.named_parameters()}
+    dp_step(dp, g, n, x, lambda_det=1e9)
+    torch.cuda.synchronize()
+    assert not bool(torch.isfinite(dp.reducer.flat).all())            # the overflow reached the weight gradients
+    assert dp.skipped_steps() == 1
+    for k, p in net.named_parameters():
+        assert torch.equal(p.detach(), before[k]), k
+    assert all(float(b.abs().max()) == 0.0 for b in opt.bufs.values())
+    l1 = dp_step(dp, g, n, x)                                         # a sane step from the untouched state ...
+    torch.cuda.synchronize()
+    assert dp.skipped_steps() == 1 and bool(torch.isfinite(dp.reducer.flat).all())
+    g2, kind2, net2, n2, x2, opt2, dp2 = fresh()                      # ... equals the first step of a fresh run, bit for bit
+    l2 = dp_step(dp2, g2, n2, x2)
+    torch.cuda.synchronize()
+    assert float(l1.detach()) == float(l2.detach()) and dp2.skipped_steps() == 0
+    moved = 0
+    for (k, a), (_, b) in zip(net.named_parameters(), net2.named_parameters()):
+        assert torch.equal(a.detach(), b.detach()), k
+        moved += int(not torch.equal(a.detach(), before[k]))
+    assert moved > 50
+    # bf16: the guard is not armed (and DBX_F16_GUARD=0 disarms it for f16)
+    net2.compute_dtype = 'bf16'
+    dp_step(dp2, g2, n2, x2)
+    assert not opt2._guard_on
+    net.engine().grad_sink = None
+    net2.engine().grad_sink = None
