@@ -35,18 +35,48 @@ FWD_GFLOP = {'DenseBox': 41.98, 'DenseBoxLM': 44.95, 'DenseBoxLMLOC': 47.81}
 STEP_GFLOP = {'DenseBox': 125.7, 'DenseBoxLM': 134.6, 'DenseBoxLMLOC': 143.2}
 MFMA_PEAK_TF = {'bf16': 2500.0, 'f16': 2500.0, 'f32': 157.3}     # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-PMC_FILE = 'r05_pmc_traffic.json'
+PMC_FILE = 'r06_pmc_traffic.json'
 
 
 def conv_flops(eng_calls):
     return sum(c['flops'] for c in eng_calls)
 
 
+def host_cpu():
+    """Model string, physical core count and logical CPU count of the host (/proc/cpuinfo; BASELINE.md section 4 asks for both)."""
+    model, cores, logical = None, set(), 0
+    try:
+        phys = core = None
+        for line in open('/proc/cpuinfo'):
+            k, _, v = line.partition(':')
+            k, v = k.strip(), v.strip()
+            if k == 'processor':
+                logical += 1
+            elif k == 'model name' and model is None:
+                model = v
+            elif k == 'physical id':
+                phys = v
+            elif k == 'core id':
+                core = v
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    return {'model': model, 'physical_cores': len(cores) or None, 'logical_cpus': logical or os.cpu_count(),
+            'sockets': len({p for p, _ in cores}) or None}
+
+
 def cpu_baseline(kind, seconds=20.0):
     """Reference algorithm on the host cores: the CPU oracle (torch fp32 nn ops + numpy bookkeeping) running the same
-    training step on a bounded sample.  Reported baseline, not a target."""
+    training step on a bounded sample (batch 8, >= 5 timed steps), torch threads = the host's physical cores.  Reported baseline,
+    not a target."""
     from oracle import densebox_oracle as O
-    n = 4
+    cpu = host_cpu()
+    threads = cpu['physical_cores'] or torch.get_num_threads()
+    torch.set_num_threads(int(threads))
+    n = 8
     net = getattr(D, kind)(synth.vgg19_standin(seed=0))
     synth.fill_params_(net, 11)
     P = {k: v.detach().clone().requires_grad_(True) for k, v in net.named_parameters()}
@@ -75,11 +105,11 @@ def cpu_baseline(kind, seconds=20.0):
         step()
         it += 1
         el = time.perf_counter() - t0
-        if el >= seconds or it >= 50:
+        if (el >= seconds and it >= 5) or it >= 50:
             break
-    out = {'value': round(n * it / el, 3), 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-           'sample': '%d training steps of %d synthetic 240x240 patches (%s, fp32, oracle/densebox_oracle.py), %.1f s'
-                     % (it, n, kind, el)}
+    out = {'value': round(n * it / el, 3), 'unit': 'patches/s', 'cores': torch.get_num_threads(), 'kind': 'port', 'host': cpu,
+           'sample': '%d training steps of %d synthetic 240x240 patches (%s, fp32, oracle/densebox_oracle.py), %.1f s, %d torch threads'
+                     % (it, n, kind, el, torch.get_num_threads())}
     # BASELINE.md section 4, cases (i) and (iii): eval forward at N = 1 / 8 and the whole-image inference chain (forward + top-K
     # decode + NMS) at 512x512 and 1920x1080, same oracle, bounded to a few seconds each
     Pd = {k: v.detach() for k, v in P.items()}
@@ -188,12 +218,25 @@ def pmc_traffic(family):
     if not m:
         return None
     code = {'bf16': 'DF16b', 'f16': 'DF16_', 'f32': 'f'}[m.group(2)]
-    want = '%sI%s%s' % (m.group(1), code, ''.join('Li%sE' % v for v in m.group(3).split(',') if v))
-    hits = [v for k, v in doc.get('kernels', {}).items() if want in k]
+    targs = [v for v in m.group(3).split(',') if v]
+    if m.group(1) == 'conv3x3_p8_kernel':
+        # the 8-phase template is <T, KS, FLAGS, EPIK> while its plan names are <T,KS> (every 3x3 / 1x1 epilogue but the fused heads) and
+        # <T,1,1> (KS 1, EPIK 1: the fused heads forward): match KS and EPIK by POSITION, the FLAGS argument in between is not part of the name
+        ks = targs[0]
+        heads = len(targs) > 1
+        pat = re.compile(r'conv3x3_p8_kernelI%sLi%sELi\d+ELi(\d+)E' % (re.escape(code), ks))
+        hits = []
+        for k, v in doc.get('kernels', {}).items():
+            mm = pat.search(k)
+            if mm and (mm.group(1) == '1') == (heads and ks == '1') and (heads or ks != '1' or mm.group(1) != '1'):
+                hits.append(v)
+    else:
+        want = '%sI%s%s' % (m.group(1), code, ''.join('Li%sE' % v for v in targs))
+        hits = [v for k, v in doc.get('kernels', {}).items() if want in k]
     if not hits:
         return None
-    # (a family may be several instantiations of one template behind the named arguments -- the 8-phase kernel's forward and gated
-    #  data-gradient epilogues: launch-weighted mean)
+    # (a family may be several instantiations of one template behind the named arguments -- the 8-phase kernel's forward, gated
+    #  data-gradient and pooling epilogues all run under one plan name: launch-weighted mean over exactly those instantiations)
     nl = sum(v['launches'] for v in hits)
     return round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in hits) / nl) if nl else None
 

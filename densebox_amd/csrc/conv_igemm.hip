@@ -2001,7 +2001,11 @@ static int conv_pool_ok_t(const dbx_conv_desc* d, const dbx_view* x, const dbx_v
     dbx_view yp = *y;
     yp.h = y->h / 2; yp.w = y->w / 2; yp.pad = 1; yp.ld = y->c; yp.c_off = 0;
     dbx_conv_plan_t pl;
+    // (a probe is not a failed call: a negative answer must not replace the caller's dbx_last_error() line)
+    char saved[512];
+    strncpy(saved, dbx_last_error(), sizeof saved - 1); saved[sizeof saved - 1] = 0;
     const int rc = conv_forward_t<T>(d, x, nullptr, nullptr, y, nullptr, nullptr, 0, nullptr, &yp, nullptr, 0, EPI2_POOL, &pl);
+    if (rc != DBX_OK) dbx_set_error("%s", saved);
     return rc == DBX_OK && pl.kernel == DBX_K_P8 ? 1 : 0;
 }
 extern "C" int dbx_conv_pool_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y) {

@@ -146,7 +146,9 @@ int dbx_conv_forward_split(const dbx_conv_desc* d, const dbx_view* x, const void
  * problems dbx_conv_pool_fusable() returns 1 for -- 16-bit 3x3 / pad 1 on congruent frames, even H and W: 64 -> 64 channels with an
  * epilogue within BIAS | RELU (the halo-tile kernel), or a layer the 8-phase kernels take (DBX_K_P8: conv2_2 -> pool2, conv3_4 ->
  * pool3, DenseBox.py:191, :204) with a (BIAS |) RELU epilogue, `ypool` N x H/2 x W/2 x y->c; anything else is DBX_ERR_ARG and the
- * caller runs the two calls. */
+ * caller runs the two calls.  dbx_conv_pool_fusable() answers for (d, x, y) only: a 1 holds for every `ypool` that is a frame of exactly
+ * N x H/2 x W/2 pixels with c == y->c channels whose base, ld and c_off are multiples of 16 bytes (any pad >= 0) -- the call checks those
+ * on the real view (DBX_ERR_ARG otherwise) -- and a 0 leaves dbx_last_error() as it was. */
 int dbx_conv_pool_fusable(const dbx_conv_desc* d, const dbx_view* x, const dbx_view* y);
 int dbx_conv_forward_pool(const dbx_conv_desc* d, const dbx_view* x, const void* w_packed, const float* bias,
                           const dbx_view* y, const dbx_view* ypool, int32_t write_full, void* stream);
