@@ -1744,6 +1744,24 @@ static int conv_forward_t(const dbx_conv_desc* d, const dbx_view* x, const void*
         // how many stages are in flight -- with the whole LDS of a CU to itself a workgroup runs a 4- or 5-deep ring instead of the
         // 3 stages that two co-resident 128-pixel workgroups can afford (DBX_CONV_VARIANT=8: off).
         const int tiles192 = (int)((Q + 191) / 192);
+        // round 6: 144-pixel tiles on SIX waves (3 x 2: 48 pixels per wave) where they still fit one round but fill more of the 256 CUs than
+        // the 192-pixel ones -- a 512 x 512 image's conv4 (64 x 64 map): 30 x 8 = 240 workgroups instead of 22 x 8 = 176, each with 3/4 of the
+        // work; conv3 (128 x 128): 116 x 2 = 232 instead of 87 x 2 = 174 (DBX_BAND144=0: the 192-pixel tiles)
+        {
+            static int b144 = -1;
+            if (b144 < 0) { const char* e = getenv("DBX_BAND144"); b144 = e ? atoi(e) : 1; }
+            const int tiles144 = (int)((Q + 143) / 144);
+            if (b144 && conv_variant() != 8 && x->n == 1) {
+                if (y->c % 128 == 0 && d->cout_pad % 128 == 0 && y->c <= 256 && tiles144 * (y->c / 128) <= 256 && tiles192 * (y->c / 128) >= 128) {
+                    a.ntile_n = y->c / 128; a.nblocks = tiles144 * a.ntile_n;
+                    DBX_SELECT(DBX_K_BAND, 144, 128, "conv3x3_band_kernel", (launch_conv_band<T, 144, 128, 4, 3, 2>(a, s)));
+                }
+                if (tiles144 * (y->c / 64) <= 256 && tiles192 * (y->c / 64) >= 128 && !(y->c % 128 == 0 && y->c <= 256 && tiles192 * (y->c / 128) >= 128)) {
+                    a.ntile_n = y->c / 64; a.nblocks = tiles144 * a.ntile_n;
+                    DBX_SELECT(DBX_K_BAND, 144, 64, "conv3x3_band_kernel", (launch_conv_band<T, 144, 64, 5, 3, 2>(a, s)));
+                }
+            }
+        }
         if (conv_variant() != 8 && x->n == 1 && y->c % 128 == 0 && d->cout_pad % 128 == 0 && y->c <= 256 && tiles192 * (y->c / 128) <= 256 &&
             tiles192 * (y->c / 128) >= 128) {
             a.ntile_n = y->c / 128; a.nblocks = tiles192 * a.ntile_n;

@@ -9,6 +9,8 @@ Tolerances (outputs are O(1); loc-type outputs O(10)); error = max |hip - ref| /
          RMS error bar 1e-3 on every map (north_star's figure; achieved 2-9e-4)
   bf16 : 8x coarser mantissa: per map, achieved + 20 % (0.57-1.8e-2); RMS bar 8e-3 (achieved <= 5.5e-3)
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -115,7 +117,7 @@ def test_whole_image_1080p(golden):
 
 @pytest.mark.parametrize('size', [(512, 512), (384, 640), (256, 1024)])
 def test_single_image_tiles_agree_with_the_fp32_path(size):
-    """Single-image maps run their own band tiles (192 x 64 / 192 x 128 / 288 x 128, one workgroup per CU with a deep LDS ring) and
+    """Single-image maps run their own band tiles (144 x 64 / 144 x 128 on six waves, 288 x 128: one workgroup per CU with a deep LDS ring) and
     the register-tournament top-K: the f16 forward of a 512 x 512-class image against the fp32 path of the same network (no reference
     fixture at these sizes: the fp32 path is pinned by the 240 x 240 / 100 x 132 / 1080p fixtures), and detect() graph replay ==
     eager == the plain forward + parse + NMS calls."""
@@ -134,10 +136,12 @@ def test_single_image_tiles_agree_with_the_fp32_path(size):
     plans = {net.engine().conv_plan(_lib.F16, net.engine().last_plan.B[a].view(), net.engine().last_plan.B[b].view(), 3, 3, 1, ci, co, 3)[1]
              for a, b, ci, co in (('a41', 'a42', 512, 512), ('a31', 'a32', 256, 256), ('a21', 'a22', 128, 128))}
     if size == (512, 512):
-        assert plans == {'conv3x3_band_kernel<f16,192,64>', 'conv3x3_band_kernel<f16,192,128>', 'conv3x3_band_kernel<f16,288,128>'}, plans
+        want_plans = {'conv3x3_band_kernel<f16,144,64>', 'conv3x3_band_kernel<f16,144,128>', 'conv3x3_band_kernel<f16,288,128>'}
+        if os.environ.get('DBX_BAND144') == '0':
+            want_plans = {'conv3x3_band_kernel<f16,192,64>', 'conv3x3_band_kernel<f16,192,128>', 'conv3x3_band_kernel<f16,288,128>'}
+        assert plans == want_plans, plans
     dets, keep = net.detect(x, K=10, nms_thresh=0.4)
     dets2, keep2 = net.detect(x, K=10, nms_thresh=0.4)                      # replay
-    import os
     os.environ['DBX_GRAPH'] = '0'
     try:
         dets3, keep3 = net.detect(x, K=10, nms_thresh=0.4)                  # eager
