@@ -34,6 +34,11 @@ struct WgradArgs {
     int nsplit;
     int hp, nstrips, units, units_per_split;   // strip walk (wgrad3x3_strip_kernel): frame height, 32-pixel column strips per row, N * nstrips
     int spi, img_rows, row0, steps_total, steps_per_split;   // compact walk (wgrad_row3_kernel): 64-row steps per image over its valid rows only
+    // round 6, wgrad3x3_strip_kernel<T, true>: dz is the backward of a 2x2 / stride 2 max pooling that is NOT in memory -- dz[y][x][c] =
+    // (arg-max nibble of window (y / 2, x / 2), channel c) == (4 | 2 (y & 1) | (x & 1)) ? pdy[y / 2][x / 2][c] : 0 (dbx_maxpool2x2_bwd_idx with relu_gate)
+    const char* pdy; const unsigned char* pidx;   // pooled gradient (channel offset applied), arg-max nibbles (dbx_maxpool2x2_idx layout, all channels)
+    int p_hp, p_wp, p_ld, p_pad, p_h, p_w;        // pdy's frame (framed rows / columns, elements per pixel, pad) and pooled extent
+    int z_h, z_w, z_pad, z_ctot, z_coff;          // the virtual dz: image extent, frame pad, channels of the pooled layer (nibble row = z_ctot / 2 bytes), view offset
 };
 
 // Workgroup -> (tile, split).  All tiles of one split stream the same frame rows of dz / x, so they should share an L2:
@@ -1475,7 +1480,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
 // dz pixels of the last strip that lie past the frame width are zeroed (they alias the next frame row).  Same tile (64 x 64,
 // all nine taps), fragment reads, MFMA schedule, slab layout and bias sums as wgrad3x3_kernel; the K range of a workgroup is
 // units_per_split consecutive (image, strip) units.
-template <typename T>
+// POOLDZ (round 6): conv1_2's weight gradient reads pool1's backward (d_a12: 472 MB at batch 64, written by dbx_maxpool2x2_bwd_idx and re-read
+// here) straight from its sources instead: the pooled gradient d_p1 (118 MB) and the arg-max nibbles (30 MB).  The dz row of a step is
+// register-staged already; a thread's chunk (eight channels of one pixel) becomes the pooled pixel's chunk ANDed with the eight 16-bit
+// masks "this pixel is the window's arg-max and the maximum was positive" decoded from one dword of nibbles (22 VALU instructions).
+template <typename T, bool POOLDZ = false>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs a) {
     static_assert(sizeof(T) == 2, "16-bit tiles");
     constexpr int R = 32, BAND = R + 2, BROWS = BAND + 2, SLOTS = 4;
@@ -1501,6 +1510,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
     const bool has2 = tid < (BAND * 8 - 256);                          // second x chunk: pixels 32, 33
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
     u32x4 areg[2], breg[2][2];                                         // two register sets: loads run TWO steps ahead
+    unsigned nreg[2] = {0u, 0u};                                        // POOLDZ: the chunk's eight arg-max nibbles
 
     f32x4 acc[9][2][2];
 #pragma unroll
@@ -1526,21 +1536,52 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
         const int n = u / a.nstrips, strip = u - n * a.nstrips;
         const int cx = strip * R;
         const long long qimg = (long long)n * a.hp * a.wp;
-        const bool a_ok = a_ch_ok && (cx + ra < a.wp);                  // dz pixels past the frame width alias the next row
-        const char* ap = a.dz + ((qimg + cx + ra) * a.dz_ld + tile_co * 64) * 2LL + ca * 16;
+        bool a_ok = a_ch_ok && (cx + ra < a.wp);                        // dz pixels past the frame width alias the next row
+        const char* ap = POOLDZ ? nullptr : a.dz + ((qimg + cx + ra) * a.dz_ld + tile_co * 64) * 2LL + ca * 16;
+        // POOLDZ: this thread's pixel column x (image coordinates) is fixed for the unit: its pooled column, the parity that selects the
+        // window position, and whether it lies inside the image at all (halo columns and the strip's overhang are zero)
+        const int zx = cx + ra - a.z_pad;
+        const int zpx = (zx >> 1) < 0 ? 0 : ((zx >> 1) < a.p_w ? (zx >> 1) : a.p_w - 1);
+        if (POOLDZ) a_ok = a_ok && zx >= 0 && zx < a.z_w;
+        const char* pp0 = nullptr; const unsigned char* ip0 = nullptr;
+        if constexpr (POOLDZ) {
+            pp0 = a.pdy + (((long long)n * a.p_hp + a.p_pad) * a.p_wp + zpx + a.p_pad) * a.p_ld * 2LL + tile_co * 128 + ca * 16;
+            ip0 = a.pidx + ((long long)n * a.p_h * a.p_w + zpx) * (a.z_ctot >> 1) + ((a.z_coff + tile_co * 64 + ca * 8) >> 1);
+        }
         const char* bp = a.x + ((qimg + cx + a.shift0 + ra) * a.x_ld + tile_ci * 64) * 2LL + ca * 16;   // pixel ra of the 34
         // frame row fy of dz; x row index xr (may be -1 or hp: the neighbouring image's halo row / the zero guard, as in the linear walk)
         // Every lane ALWAYS loads (masked lanes read valid neighbouring memory and are zeroed at the LDS store; lanes without a
         // second x chunk re-read their first): loads inside divergent or uniform branches make the compiler's counter
         // bookkeeping fall back to s_waitcnt vmcnt(0) in front of the next issue, which serialises the two-step prefetch.
         const long long b2 = has2 ? 32 * b_row : 0;
-        auto gload_a = [&](int set, int fy) { areg[set] = *(const u32x4*)(ap + (long long)fy * a.wp * a_row); };
+        auto gload_a = [&](int set, int fy) {
+            if constexpr (POOLDZ) {
+                int py = (fy - a.z_pad) >> 1;                            // (uniform) halo rows read a valid row, zeroed at the LDS store
+                py = py < 0 ? 0 : (py < a.p_h ? py : a.p_h - 1);
+                areg[set] = *(const u32x4*)(pp0 + (long long)py * a.p_wp * a.p_ld * 2LL);
+                nreg[set] = *(const unsigned*)(ip0 + (long long)py * a.p_w * (a.z_ctot >> 1));
+            } else areg[set] = *(const u32x4*)(ap + (long long)fy * a.wp * a_row);
+        };
         auto gload_b = [&](int set, int xr) {
             breg[set][0] = *(const u32x4*)(bp + (long long)xr * a.wp * b_row);
             breg[set][1] = *(const u32x4*)(bp + (long long)xr * a.wp * b_row + b2);
         };
-        auto lstore_a = [&](int set, int buf) {
-            if (!a_ok) areg[set] = zero4;
+        auto lstore_a = [&](int set, int buf, int fy) {
+            if constexpr (POOLDZ) {
+                const int zy = fy - a.z_pad;
+                // nibble == 4 | position (bit 2: the window's maximum was > 0, the ReLU gate) -> an all-ones / zero mask per 16-bit element
+                const unsigned want = (4u | (unsigned)((zy & 1) << 1) | (unsigned)(zx & 1)) * 0x11111111u;
+                unsigned t = nreg[set] ^ want;
+                t |= t >> 1; t |= t >> 2;
+                const unsigned hit = ~t & 0x11111111u;                  // bit 4 c: channel c of the chunk routes its gradient to this pixel
+                u32x4 v = areg[set];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int lo = (int)(hit << (31 - 8 * d)) >> 31, hi = (int)(hit << (27 - 8 * d)) >> 31;    // (v_bfe_i32: the bit, sign-extended)
+                    v[d] &= ((unsigned)lo & 0xffffu) | ((unsigned)hi & 0xffff0000u);
+                }
+                areg[set] = (a_ok && zy >= 0 && zy < a.z_h) ? v : zero4;
+            } else if (!a_ok) areg[set] = zero4;
             *(u32x4*)(As + buf * A_BYTES + swz16<64>(ra, ca * 16)) = areg[set];
         };
         auto lstore_b = [&](int set, int xr) {
@@ -1552,7 +1593,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
         __syncthreads();                                                 // the previous unit's last reads are done
 #pragma unroll 1
         for (int i = 0; i < 3; ++i) { gload_b(0, a.shift0 + i); lstore_b(0, a.shift0 + i); }
-        gload_a(0, 0); lstore_a(0, 0); if (do_bias) bias_acc(0);
+        gload_a(0, 0); lstore_a(0, 0, 0); if (do_bias) bias_acc(0);
         const int nsteps = a.hp;
         { const int r1 = nsteps > 1 ? 1 : 0; gload_a(1, r1); gload_b(1, r1 + 2 + a.shift0); }   // step 1's operands: set 1
         __syncthreads();
@@ -1607,7 +1648,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
                 }
             }
             // the new x row goes to the slot of row s + shift0 - 1 (dead since the previous step's barrier), dz to the other buffer
-            if (s + 1 < nsteps) { lstore_a(SET ^ 1, buf ^ 1); if (do_bias) bias_acc(SET ^ 1); lstore_b(SET ^ 1, s + 3 + a.shift0); }
+            if (s + 1 < nsteps) { lstore_a(SET ^ 1, buf ^ 1, s + 1); if (do_bias) bias_acc(SET ^ 1); lstore_b(SET ^ 1, s + 3 + a.shift0); }
             __syncthreads();
         };
         for (int s = 0; s < nsteps; s += 2) {
@@ -2034,16 +2075,18 @@ extern "C" int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_
     return DBX_OK;
 }
 
+// dz as the backward of a max pooling that is not in memory (dbx_conv_wgrad_pool_dz): the pooled gradient and the arg-max nibbles
+struct PoolDz { const dbx_view* dy; const unsigned char* idx; int ctot; };
 template <typename T>
 static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cpad, int co, int ci, float* dw, float* db,
-                   void* scratch, int accumulate, hipStream_t s, int ci_total, int ci_off, const GenHid* gen = nullptr) {
+                   void* scratch, int accumulate, hipStream_t s, int ci_total, int ci_off, const GenHid* gen = nullptr, const PoolDz* pz = nullptr) {
     DBX_REQUIRE(ci_off >= 0 && ci_off + ci <= ci_total, "wgrad: column slice [%d, %d) outside the %d input channels of dw", ci_off, ci_off + ci, ci_total);
     constexpr int ES = sizeof(T);
     DBX_REQUIRE(dz->n == x->n && dz->h + 2 * dz->pad == x->h + 2 * x->pad && dz->w + 2 * dz->pad == x->w + 2 * x->pad,
                 "wgrad: dz frame %dx%d(+%d) and x frame %dx%d(+%d) are not congruent", dz->h, dz->w, dz->pad, x->h, x->w, x->pad);
     DBX_REQUIRE(x->h + 2 * cpad - kh + 1 == dz->h && x->w + 2 * cpad - kw + 1 == dz->w, "wgrad: dz is not the conv output shape");
     DBX_REQUIRE(co <= dz->c && ci <= x->c, "wgrad: real channel counts exceed the views");
-    DBX_REQUIRE(((size_t)dz->ptr % 16) == 0 && ((size_t)x->ptr % 16) == 0 && (dz->ld * ES) % 16 == 0 && (x->ld * ES) % 16 == 0 &&
+    DBX_REQUIRE((pz || ((size_t)dz->ptr % 16) == 0) && ((size_t)x->ptr % 16) == 0 && (dz->ld * ES) % 16 == 0 && (x->ld * ES) % 16 == 0 &&
                     (dz->c_off * ES) % 16 == 0 && (x->c_off * ES) % 16 == 0 && (dz->c * ES) % 16 == 0 && (x->c * ES) % 16 == 0,
                 "wgrad: 16-byte alignment");
     const WgradPlan p = wgrad_plan(DType<T>::id, dz, x, kh, kw);
@@ -2060,6 +2103,18 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.spi = p.spi; a.img_rows = (dz->h + 2 * dz->pad) * (dz->w + 2 * dz->pad); a.row0 = (dz->w + 2 * dz->pad) * dz->pad;
     a.steps_total = p.steps_total; a.steps_per_split = p.steps_per_split;
     DBX_REQUIRE(!gen || (p.wide2 && p.spi > 0 && sizeof(T) == 2), "wgrad with a generated hidden gradient: needs the wide 1x1 kernel on padded frames of >= 32 columns");
+    DBX_REQUIRE(!pz || (p.alltaps && p.strip && !p.wide2 && !p.all9 && !p.c8 && sizeof(T) == 2), "wgrad with a pooling backward as dz: needs the 3x3 column-strip kernel (dbx_conv_wgrad_pool_dz_ok)");
+    a.pdy = nullptr; a.pidx = nullptr; a.p_hp = a.p_wp = a.p_ld = a.p_pad = a.p_h = a.p_w = a.z_h = a.z_w = a.z_pad = a.z_ctot = a.z_coff = 0;
+    if (pz) {
+        const dbx_view* dy = pz->dy;
+        DBX_REQUIRE(dy->n == dz->n && dy->h == dz->h / 2 && dy->w == dz->w / 2 && dz->h % 2 == 0 && dz->w % 2 == 0 && dy->c == dz->c && dy->c_off == dz->c_off &&
+                        ((size_t)dy->ptr % 16) == 0 && (dy->ld * ES) % 16 == 0 && (dy->c_off * ES) % 16 == 0 && ((size_t)pz->idx % 4) == 0 && dz->c_off % 8 == 0 &&
+                        pz->ctot % 8 == 0 && dz->c_off + dz->c <= pz->ctot,
+                    "wgrad pool dz: dy is the pooled map of dz (even extent, same channels / channel offset), 16-byte aligned, idx 4-byte aligned");
+        a.pdy = (const char*)dy->ptr + (size_t)dy->c_off * ES; a.pidx = pz->idx;
+        a.p_hp = dy->h + 2 * dy->pad; a.p_wp = dy->w + 2 * dy->pad; a.p_ld = dy->ld; a.p_pad = dy->pad; a.p_h = dy->h; a.p_w = dy->w;
+        a.z_h = dz->h; a.z_w = dz->w; a.z_pad = dz->pad; a.z_ctot = pz->ctot; a.z_coff = dz->c_off;
+    }
     if (p.wide2) {
         if constexpr (sizeof(T) == 2) {
             constexpr int smem = 4 * 2 * 32 * 512;
@@ -2111,7 +2166,8 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
                 if (p.strip) {
                     constexpr int smem2 = 2 * 32 * 128 + 4 * 36 * 128;
                     a.hp = dz->h + 2 * dz->pad; a.nstrips = p.nstrips; a.units = p.units; a.units_per_split = p.units_per_split;
-                    hipLaunchKernelGGL((wgrad3x3_strip_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), smem2, s, a);
+                    if (pz) hipLaunchKernelGGL((wgrad3x3_strip_kernel<T, true>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), smem2, s, a);
+                    else hipLaunchKernelGGL((wgrad3x3_strip_kernel<T, false>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), smem2, s, a);
                 } else
                 hipLaunchKernelGGL((wgrad3x3_kernel<T>), dim3(p.tiles_co * p.tiles_ci * p.splits), dim3(256), smem + pad, s, a);
             }
@@ -2181,6 +2237,30 @@ extern "C" int dbx_conv_wgrad_slice(int32_t dtype, const dbx_view* dz, const dbx
                                     int32_t accumulate, void* stream) {
     if (!dz || !x || !dw_oihw || !scratch) { dbx_set_error("wgrad: null argument"); return DBX_ERR_ARG; }
     DBX_DISPATCH_DTYPE(dtype, wgrad_t, dz, x, kh, kw, cpad, co, ci, dw_oihw, db, scratch, accumulate, (hipStream_t)stream, dw_ci_total, dw_ci_off);
+}
+
+// ---------------------------------------------------------------------------------------------- dz = a max pooling's backward, not in memory
+// dbx_conv_wgrad_pool_dz (round 6): dbx_maxpool2x2_bwd_idx(idx, dy, dz, relu_gate) + dbx_conv_wgrad(dz, x, 3x3) without dz in memory
+// (wgrad3x3_strip_kernel<T, true>).  dz: the SHAPE of the un-pooled gradient (frame congruent with x; ptr is not dereferenced).
+template <typename T>
+static int wgrad_pool_dz_t(const dbx_view* dy, const void* idx, int idx_ctot, const dbx_view* dz, const dbx_view* x, int kh, int kw, int cpad, int co, int ci,
+                           float* dw, float* db, void* scratch, int accumulate, hipStream_t s) {
+    if constexpr (sizeof(T) != 2) { dbx_set_error("wgrad pool dz: 16-bit compute types only"); return DBX_ERR_DTYPE; }
+    else {
+        PoolDz pz{dy, (const unsigned char*)idx, idx_ctot};
+        return wgrad_t<T>(dz, x, kh, kw, cpad, co, ci, dw, db, scratch, accumulate, s, ci, 0, nullptr, &pz);
+    }
+}
+extern "C" int dbx_conv_wgrad_pool_dz_ok(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw) {
+    if (!dz || !x || (dtype != DBX_F16 && dtype != DBX_BF16) || dz->h % 2 || dz->w % 2) return 0;
+    const WgradPlan p = wgrad_plan(dtype, dz, x, kh, kw);
+    return (p.alltaps && p.strip && !p.wide2 && !p.all9 && !p.c8) ? 1 : 0;
+}
+extern "C" int dbx_conv_wgrad_pool_dz(int32_t dtype, const dbx_view* dy, const void* idx, int32_t idx_channels, const dbx_view* dz, const dbx_view* x,
+                                      int32_t kh, int32_t kw, int32_t cpad, int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch,
+                                      int32_t accumulate, void* stream) {
+    if (!dy || !idx || !dz || !x || !dw_oihw || !scratch) { dbx_set_error("wgrad pool dz: null argument"); return DBX_ERR_ARG; }
+    DBX_DISPATCH_DTYPE(dtype, wgrad_pool_dz_t, dy, idx, idx_channels, dz, x, kh, kw, cpad, co, ci, dw_oihw, db, scratch, accumulate, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------- heads: dW1 with the hidden gradient generated

@@ -1022,8 +1022,9 @@ class Engine:
             P.B['d_hid'] = b
         return b
 
-    def _wgrad(self, dt, dz, x, kh, kw, cpad, co, ci, dw, db, accumulate=0, ci_total=None, ci_off=0, gen=None):
-        """gen = (d_out view, w2 pointers, ks, nh, use_hash, seed): dz is the heads' hidden gradient, generated in the kernel (dz: shape only)."""
+    def _wgrad(self, dt, dz, x, kh, kw, cpad, co, ci, dw, db, accumulate=0, ci_total=None, ci_off=0, gen=None, pool=None):
+        """gen = (d_out view, w2 pointers, ks, nh, use_hash, seed): dz is the heads' hidden gradient, generated in the kernel (dz: shape only).
+        pool = (dy view, nibbles tensor, channels of the pooled layer): dz is that pooling's backward, taken from its sources (dz: shape only)."""
         need = self.L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(dz), C.byref(x), kh, kw)
         if getattr(self, '_wg_scratch', None) is None or self._wg_scratch.numel() < need:
             self._wg_scratch = torch.empty(int(need * 1.25) + 1024, dtype=torch.uint8, device=dw.device)
@@ -1031,7 +1032,11 @@ class Engine:
         if prof is not None:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if gen is not None:
+        if pool is not None:
+            dyv, nib, nch = pool
+            check(self.L.dbx_conv_wgrad_pool_dz(dt, C.byref(dyv), ptr(nib), nch, C.byref(dz), C.byref(x), kh, kw, cpad, co, ci, ptr(dw), ptr(db),
+                                                ptr(self._wg_scratch), accumulate, stream_ptr()))
+        elif gen is not None:
             dov, w2p, ks, nh, use_hash, seed = gen
             check(self.L.dbx_heads1_wgrad_gen(dt, C.byref(dov), C.byref(x), w2p, ks, nh, use_hash, seed, ci, ptr(dw), ci_total, ci_off, ptr(db),
                                               ptr(self._wg_scratch), stream_ptr()))
@@ -1048,6 +1053,8 @@ class Engine:
             name = buf.value.decode()
             if gen is not None:
                 name = name.replace('>', ',gen>')
+            if pool is not None:
+                name = name.replace('>', ',pool>')
             prof.append({'kernel': name, 'flops': 2.0 * dz.n * dz.h * dz.w * kh * kw * ci * co, 'start': ev0, 'end': ev1})
 
     def backward_raw(self, grad_outs):
@@ -1103,9 +1110,15 @@ class Engine:
 
         def conv_bwd(stem, dz, x, kh, kw, cpad, co, ci):
             dw, db = new_grad(stem + '.weight'), new_grad(stem + '.bias')
+            # conv1_2's weight gradient takes pool1's backward from its sources -- d_p1 and the arg-max nibbles, 148 MB at batch 64 -- instead of
+            # re-reading the 472-MB d_a12 (dbx_conv_wgrad_pool_dz; DBX_POOL_WGRAD=0: from the map)
+            pool = None
+            if stem == 'conv1_2_1' and P.pool_idx is not None and os.environ.get('DBX_POOL_WGRAD', '1') != '0' and \
+                    L.dbx_conv_wgrad_pool_dz_ok(dt, C.byref(dz), C.byref(x), kh, kw):
+                pool = (B['d_p1'].view(), P.pool_idx['a12'], 64)
 
             def run():
-                self._wgrad(dt, dz, x, kh, kw, cpad, co, ci, dw, db)
+                self._wgrad(dt, dz, x, kh, kw, cpad, co, ci, dw, db, pool=pool)
                 if sink is not None:
                     sink.ready([stem + '.weight', stem + '.bias'])
             on_side(run)

@@ -45,7 +45,7 @@ const char* dbx_last_error(void);
  *   5  (round 4) dbx_sgd_pack_step and dbx_heads_forward_fused_heads added; nothing changed
  *   6  (round 5) dbx_conv_plan may name DBX_K_P8 (the 8-phase kernel: plain packed weights); dbx_heads_forward_fusable returns WHICH kernel
  *      takes the fused heads forward (1 = ws / fragment-order weights as before, 2 = 8-phase / plain weights + plain second-weight image)
- *   7  (round 6) additions only: dbx_grad_guard, dbx_sgd_step_guarded, dbx_sgd_pack_step_guarded (f16 overflow guard); the heads-gen
+ *   7  (round 6) additions only: dbx_grad_guard, dbx_sgd_step_guarded, dbx_sgd_pack_step_guarded (f16 overflow guard), dbx_conv_wgrad_pool_dz; the heads-gen
  *      entry points accept DBX_F32 (reference instantiations for the parity suite) */
 #define DBX_ABI_VERSION 7
 int dbx_version(void);
@@ -219,6 +219,17 @@ int dbx_head2_backward(int32_t dtype, const dbx_view* d_out, const dbx_view* hid
 int dbx_head2_backward_up(int32_t dtype, const dbx_view* d_out, const dbx_view* hid, const float* const* w2, const int32_t* k,
                           int32_t nh, const dbx_view* d_hid, const uint8_t* dropmask, int32_t dropmask_ld, int32_t use_hash,
                           uint32_t drop_seed, float* const* dw, float* const* db, void* scratch, const dbx_view* d_g44, void* stream);
+/* Round 6: a weight gradient whose dz is the backward of a 2x2 / stride 2 max pooling need not see that map in memory either:
+ * dbx_conv_wgrad_pool_dz == dbx_maxpool2x2_bwd_idx(idx, dy, dz, accumulate 0, relu_gate 1) followed by dbx_conv_wgrad(dz, x, ...), bit for bit,
+ * without dz (conv1_2's weight gradient behind pool1, DenseBox.py:186-187 backwards: 148 MB of dy + nibbles read instead of the 472 MB map).
+ * dy: the pooled gradient (N x H/2 x W/2, same channels / channel offset as dz); idx: the arg-max nibbles of the WHOLE pooled layer
+ * (dbx_maxpool2x2_idx layout, idx_channels channels per pooled pixel); dz: the shape of the un-pooled gradient on its frame (congruent with
+ * x; ptr is not read).  Exists where dbx_conv_wgrad_pool_dz_ok() returns 1 (16-bit, even H / W, the 3x3 column-strip kernel's shapes);
+ * scratch as dbx_conv_wgrad_scratch_bytes(dz, x). */
+int dbx_conv_wgrad_pool_dz_ok(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw);
+int dbx_conv_wgrad_pool_dz(int32_t dtype, const dbx_view* dy, const void* idx, int32_t idx_channels, const dbx_view* dz, const dbx_view* x,
+                           int32_t kh, int32_t kw, int32_t cpad, int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch,
+                           int32_t accumulate, void* stream);
 /* Round 4: the hidden gradient need not exist in memory.  d_hid = keep * scale * (d_out W2) has <= 8 input channels per head, so
  * its consumers GENERATE it, 32 channels x 32 pixels per MFMA (W2 and d_out in the compute dtype, keep bits from the forward's hash):
  *   dbx_head2_backward_up with d_hid->ptr == NULL (the view's shape still describes the map) does not store it (one-pass form
