@@ -97,7 +97,7 @@ SIGNATURES = {
     'dbx_conv_wgrad': (C.c_int, [_I32, _PV, _PV, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _VP]),
     'dbx_conv_wgrad_slice': (C.c_int, [_I32, _PV, _PV, _I32, _I32, _I32, _I32, _I32, _VP, _I32, _I32, _VP, _VP, _I32, _VP]),
     'dbx_conv_wgrad_pool_dz_ok': (C.c_int, [_I32, _PV, _PV, _I32, _I32]),
-    'dbx_conv_wgrad_pool_dz': (C.c_int, [_I32, _PV, _VP, _I32, _PV, _PV, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _VP]),
+    'dbx_conv_wgrad_pool_dz': (C.c_int, [_I32, _PV, _VP, _I32, _PV, _PV, _I32, _I32, _I32, _I32, _I32, _VP, _VP, _VP, _I32, _I32, _VP]),
     'dbx_head2_backward_up_fused': (C.c_int, [_I32, _PV, _PV]),
     'dbx_heads1_wgrad_gen_ok': (C.c_int, [_I32, _PV, _I32]),
     'dbx_heads1_dgrad_gen': (C.c_int, [_I32, _PV, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I32, _I32, C.c_uint32, _VP, _PV, _PV, _VP]),

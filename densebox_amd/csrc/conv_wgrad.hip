@@ -39,6 +39,7 @@ struct WgradArgs {
     const char* pdy; const unsigned char* pidx;   // pooled gradient (channel offset applied), arg-max nibbles (dbx_maxpool2x2_idx layout, all channels)
     int p_hp, p_wp, p_ld, p_pad, p_h, p_w;        // pdy's frame (framed rows / columns, elements per pixel, pad) and pooled extent
     int z_h, z_w, z_pad, z_ctot, z_coff;          // the virtual dz: image extent, frame pad, channels of the pooled layer (nibble row = z_ctot / 2 bytes), view offset
+    char* zout;                                   // optional: the framed dz map itself is ALSO written (channel offset applied) -- the pooling backward as a by-product
 };
 
 // Workgroup -> (tile, split).  All tiles of one split stream the same frame rows of dz / x, so they should share an L2:
@@ -1544,7 +1545,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
         const int zpx = (zx >> 1) < 0 ? 0 : ((zx >> 1) < a.p_w ? (zx >> 1) : a.p_w - 1);
         if (POOLDZ) a_ok = a_ok && zx >= 0 && zx < a.z_w;
         const char* pp0 = nullptr; const unsigned char* ip0 = nullptr;
+        char* zp0 = nullptr;
         if constexpr (POOLDZ) {
+            if (a.zout && tile_ci == 0) zp0 = a.zout + ((qimg + cx + ra) * a.dz_ld + tile_co * 64) * 2LL + ca * 16;
             pp0 = a.pdy + (((long long)n * a.p_hp + a.p_pad) * a.p_wp + zpx + a.p_pad) * a.p_ld * 2LL + tile_co * 128 + ca * 16;
             ip0 = a.pidx + ((long long)n * a.p_h * a.p_w + zpx) * (a.z_ctot >> 1) + ((a.z_coff + tile_co * 64 + ca * 8) >> 1);
         }
@@ -1583,6 +1586,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
                 areg[set] = (a_ok && zy >= 0 && zy < a.z_h) ? v : zero4;
             } else if (!a_ok) areg[set] = zero4;
             *(u32x4*)(As + buf * A_BYTES + swz16<64>(ra, ca * 16)) = areg[set];
+            if constexpr (POOLDZ) {
+                // the un-pooled gradient map as a by-product (its other consumer, conv1_2's data gradient, reads it): every frame pixel of the
+                // strip's real columns exactly once over the grid, halo rows / columns as zeros -- dbx_maxpool2x2_bwd_idx's launch goes away
+                if (zp0 && a_ch_ok && cx + ra < a.wp) *(u32x4*)(zp0 + (long long)fy * a.wp * a_row) = areg[set];
+            }
         };
         auto lstore_b = [&](int set, int xr) {
             const int sb = ((xr + 4) & 3) * BROWS;
@@ -2076,7 +2084,7 @@ extern "C" int dbx_conv_wgrad_plan(int32_t dtype, const dbx_view* dz, const dbx_
 }
 
 // dz as the backward of a max pooling that is not in memory (dbx_conv_wgrad_pool_dz): the pooled gradient and the arg-max nibbles
-struct PoolDz { const dbx_view* dy; const unsigned char* idx; int ctot; };
+struct PoolDz { const dbx_view* dy; const unsigned char* idx; int ctot; int write_dz; };
 template <typename T>
 static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cpad, int co, int ci, float* dw, float* db,
                    void* scratch, int accumulate, hipStream_t s, int ci_total, int ci_off, const GenHid* gen = nullptr, const PoolDz* pz = nullptr) {
@@ -2104,6 +2112,7 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
     a.steps_total = p.steps_total; a.steps_per_split = p.steps_per_split;
     DBX_REQUIRE(!gen || (p.wide2 && p.spi > 0 && sizeof(T) == 2), "wgrad with a generated hidden gradient: needs the wide 1x1 kernel on padded frames of >= 32 columns");
     DBX_REQUIRE(!pz || (p.alltaps && p.strip && !p.wide2 && !p.all9 && !p.c8 && sizeof(T) == 2), "wgrad with a pooling backward as dz: needs the 3x3 column-strip kernel (dbx_conv_wgrad_pool_dz_ok)");
+    a.zout = nullptr;
     a.pdy = nullptr; a.pidx = nullptr; a.p_hp = a.p_wp = a.p_ld = a.p_pad = a.p_h = a.p_w = a.z_h = a.z_w = a.z_pad = a.z_ctot = a.z_coff = 0;
     if (pz) {
         const dbx_view* dy = pz->dy;
@@ -2114,6 +2123,10 @@ static int wgrad_t(const dbx_view* dz, const dbx_view* x, int kh, int kw, int cp
         a.pdy = (const char*)dy->ptr + (size_t)dy->c_off * ES; a.pidx = pz->idx;
         a.p_hp = dy->h + 2 * dy->pad; a.p_wp = dy->w + 2 * dy->pad; a.p_ld = dy->ld; a.p_pad = dy->pad; a.p_h = dy->h; a.p_w = dy->w;
         a.z_h = dz->h; a.z_w = dz->w; a.z_pad = dz->pad; a.z_ctot = pz->ctot; a.z_coff = dz->c_off;
+        if (pz->write_dz) {
+            DBX_REQUIRE(dz->ptr && ((size_t)dz->ptr % 16) == 0, "wgrad pool dz: write_dz needs the dz map's memory");
+            a.zout = (char*)dz->ptr + (size_t)dz->c_off * ES;
+        }
     }
     if (p.wide2) {
         if constexpr (sizeof(T) == 2) {
@@ -2244,10 +2257,10 @@ extern "C" int dbx_conv_wgrad_slice(int32_t dtype, const dbx_view* dz, const dbx
 // (wgrad3x3_strip_kernel<T, true>).  dz: the SHAPE of the un-pooled gradient (frame congruent with x; ptr is not dereferenced).
 template <typename T>
 static int wgrad_pool_dz_t(const dbx_view* dy, const void* idx, int idx_ctot, const dbx_view* dz, const dbx_view* x, int kh, int kw, int cpad, int co, int ci,
-                           float* dw, float* db, void* scratch, int accumulate, hipStream_t s) {
+                           float* dw, float* db, void* scratch, int accumulate, int write_dz, hipStream_t s) {
     if constexpr (sizeof(T) != 2) { dbx_set_error("wgrad pool dz: 16-bit compute types only"); return DBX_ERR_DTYPE; }
     else {
-        PoolDz pz{dy, (const unsigned char*)idx, idx_ctot};
+        PoolDz pz{dy, (const unsigned char*)idx, idx_ctot, write_dz};
         return wgrad_t<T>(dz, x, kh, kw, cpad, co, ci, dw, db, scratch, accumulate, s, ci, 0, nullptr, &pz);
     }
 }
@@ -2258,9 +2271,9 @@ extern "C" int dbx_conv_wgrad_pool_dz_ok(int32_t dtype, const dbx_view* dz, cons
 }
 extern "C" int dbx_conv_wgrad_pool_dz(int32_t dtype, const dbx_view* dy, const void* idx, int32_t idx_channels, const dbx_view* dz, const dbx_view* x,
                                       int32_t kh, int32_t kw, int32_t cpad, int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch,
-                                      int32_t accumulate, void* stream) {
+                                      int32_t accumulate, int32_t write_dz, void* stream) {
     if (!dy || !idx || !dz || !x || !dw_oihw || !scratch) { dbx_set_error("wgrad pool dz: null argument"); return DBX_ERR_ARG; }
-    DBX_DISPATCH_DTYPE(dtype, wgrad_pool_dz_t, dy, idx, idx_channels, dz, x, kh, kw, cpad, co, ci, dw_oihw, db, scratch, accumulate, (hipStream_t)stream);
+    DBX_DISPATCH_DTYPE(dtype, wgrad_pool_dz_t, dy, idx, idx_channels, dz, x, kh, kw, cpad, co, ci, dw_oihw, db, scratch, accumulate, write_dz, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------- heads: dW1 with the hidden gradient generated

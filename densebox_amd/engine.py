@@ -1033,9 +1033,9 @@ class Engine:
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         if pool is not None:
-            dyv, nib, nch = pool
+            dyv, nib, nch, write_dz = pool
             check(self.L.dbx_conv_wgrad_pool_dz(dt, C.byref(dyv), ptr(nib), nch, C.byref(dz), C.byref(x), kh, kw, cpad, co, ci, ptr(dw), ptr(db),
-                                                ptr(self._wg_scratch), accumulate, stream_ptr()))
+                                                ptr(self._wg_scratch), accumulate, write_dz, stream_ptr()))
         elif gen is not None:
             dov, w2p, ks, nh, use_hash, seed = gen
             check(self.L.dbx_heads1_wgrad_gen(dt, C.byref(dov), C.byref(x), w2p, ks, nh, use_hash, seed, ci, ptr(dw), ci_total, ci_off, ptr(db),
@@ -1054,7 +1054,7 @@ class Engine:
             if gen is not None:
                 name = name.replace('>', ',gen>')
             if pool is not None:
-                name = name.replace('>', ',pool>')
+                name = name.replace('>', ',pool+dz>' if pool[3] else ',pool>')
             prof.append({'kernel': name, 'flops': 2.0 * dz.n * dz.h * dz.w * kh * kw * ci * co, 'start': ev0, 'end': ev1})
 
     def backward_raw(self, grad_outs):
@@ -1111,11 +1111,11 @@ class Engine:
         def conv_bwd(stem, dz, x, kh, kw, cpad, co, ci):
             dw, db = new_grad(stem + '.weight'), new_grad(stem + '.bias')
             # conv1_2's weight gradient takes pool1's backward from its sources -- d_p1 and the arg-max nibbles, 148 MB at batch 64 -- instead of
-            # re-reading the 472-MB d_a12 (dbx_conv_wgrad_pool_dz; DBX_POOL_WGRAD=0: from the map)
+            # re-reading the 472-MB d_a12 (dbx_conv_wgrad_pool_dz; DBX_POOL_WGRAD=0: from the map) and WRITES that map as a by-product for
+            # conv1_2's data gradient, which runs behind it: pool1's backward has no launch of its own (DBX_POOL_WGRAD=2: keeps the launch)
             pool = None
-            if stem == 'conv1_2_1' and P.pool_idx is not None and os.environ.get('DBX_POOL_WGRAD', '1') != '0' and \
-                    L.dbx_conv_wgrad_pool_dz_ok(dt, C.byref(dz), C.byref(x), kh, kw):
-                pool = (B['d_p1'].view(), P.pool_idx['a12'], 64)
+            if stem == 'conv1_2_1' and pool12:
+                pool = (B['d_p1'].view(), P.pool_idx['a12'], 64, 1 if pool12 == 1 else 0)
 
             def run():
                 self._wgrad(dt, dz, x, kh, kw, cpad, co, ci, dw, db, pool=pool)
@@ -1341,6 +1341,13 @@ class Engine:
             ('conv1_1_1', 'd_a11', 'x0', 3, 64, None, None),
         ]
         fused11 = False
+        # pool1's backward inside conv1_2's weight gradient?  0: no; 1: yes, and that kernel writes d_a12 for the data gradient; 2: yes, the map
+        # still comes from dbx_maxpool2x2_bwd_idx (A/B)
+        pool12 = 0
+        if P.pool_idx is not None and os.environ.get('DBX_POOL_WGRAD', '1') != '0' and \
+                L.dbx_conv_wgrad_pool_dz_ok(dt, C.byref(B['d_a12'].view()), C.byref(B['a11'].view()), 3, 3):
+            # (the by-product needs the weight gradient IN FRONT of the data gradient on one stream: not under the side-stream schedule)
+            pool12 = 2 if (os.environ.get('DBX_POOL_WGRAD') == '2' or side is not None) else 1
         for item in chain:
             if item[0] == 'conv1_1_1' and fused11:
                 continue                                # its weight gradient came out of conv1_2's data-gradient kernel
@@ -1370,6 +1377,8 @@ class Engine:
                     continue
             if item[0] == 'pool':
                 _, xname, dyname, dxname, acc = item
+                if xname == 'a12' and pool12 == 1:
+                    continue                            # (conv1_2's weight gradient produces d_a12 on its way)
                 if P.pool_idx is not None:
                     check(L.dbx_maxpool2x2_bwd_idx(dt, ptr(P.pool_idx[xname]), C.byref(B[dyname].view()), C.byref(B[dxname].view()),
                                                    acc, 1, s))

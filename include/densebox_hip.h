@@ -224,12 +224,14 @@ int dbx_head2_backward_up(int32_t dtype, const dbx_view* d_out, const dbx_view* 
  * without dz (conv1_2's weight gradient behind pool1, DenseBox.py:186-187 backwards: 148 MB of dy + nibbles read instead of the 472 MB map).
  * dy: the pooled gradient (N x H/2 x W/2, same channels / channel offset as dz); idx: the arg-max nibbles of the WHOLE pooled layer
  * (dbx_maxpool2x2_idx layout, idx_channels channels per pooled pixel); dz: the shape of the un-pooled gradient on its frame (congruent with
- * x; ptr is not read).  Exists where dbx_conv_wgrad_pool_dz_ok() returns 1 (16-bit, even H / W, the 3x3 column-strip kernel's shapes);
+ * x; ptr is not read -- unless write_dz != 0: then the kernel ALSO writes the un-pooled gradient map there, every pixel of the frame incl. its
+ * zero halo, bit for bit dbx_maxpool2x2_bwd_idx's, for a consumer that still wants it in memory: the pooling backward's own launch goes
+ * away).  Exists where dbx_conv_wgrad_pool_dz_ok() returns 1 (16-bit, even H / W, the 3x3 column-strip kernel's shapes);
  * scratch as dbx_conv_wgrad_scratch_bytes(dz, x). */
 int dbx_conv_wgrad_pool_dz_ok(int32_t dtype, const dbx_view* dz, const dbx_view* x, int32_t kh, int32_t kw);
 int dbx_conv_wgrad_pool_dz(int32_t dtype, const dbx_view* dy, const void* idx, int32_t idx_channels, const dbx_view* dz, const dbx_view* x,
                            int32_t kh, int32_t kw, int32_t cpad, int32_t co, int32_t ci, float* dw_oihw, float* db, void* scratch,
-                           int32_t accumulate, void* stream);
+                           int32_t accumulate, int32_t write_dz, void* stream);
 /* Round 4: the hidden gradient need not exist in memory.  d_hid = keep * scale * (d_out W2) has <= 8 input channels per head, so
  * its consumers GENERATE it, 32 channels x 32 pixels per MFMA (W2 and d_out in the compute dtype, keep bits from the forward's hash):
  *   dbx_head2_backward_up with d_hid->ptr == NULL (the view's shape still describes the map) does not store it (one-pass form

@@ -1339,10 +1339,20 @@ def test_conv_wgrad_with_the_pooling_backward_as_dz_equals_the_two_calls(shape, 
     dw2 = torch.full((c, c, 3, 3), 7.0, device='cuda'); db2 = torch.full((c,), 7.0, device='cuda')
     check(L.dbx_conv_wgrad(dt, C.byref(zv), C.byref(xv), 3, 3, 1, c, c, ptr(dw1), ptr(db1), ptr(sc), 0, stream_ptr()))
     zshape = View(None, n, h, w, 1, c, 0, c)                                          # the map is NOT handed over: shape only
-    check(L.dbx_conv_wgrad_pool_dz(dt, C.byref(dyv), ptr(idx), c, C.byref(zshape), C.byref(xv), 3, 3, 1, c, c, ptr(dw2), ptr(db2), ptr(sc), 0, stream_ptr()))
+    check(L.dbx_conv_wgrad_pool_dz(dt, C.byref(dyv), ptr(idx), c, C.byref(zshape), C.byref(xv), 3, 3, 1, c, c, ptr(dw2), ptr(db2), ptr(sc), 0, 0, stream_ptr()))
+    # write_dz: the same call also leaves the un-pooled gradient map in memory (frame incl. its zero halo; here the destination starts as garbage)
+    fz3, tz3, zv3 = framed(torch.full((n, c, h, w), 3.0), 1, tdt)
+    tz3[:, 0] = 5.0; tz3[:, -1] = 5.0; tz3[:, :, 0] = 5.0; tz3[:, :, -1] = 5.0
+    guard_before = fz3.clone()
+    dw3 = torch.full((c, c, 3, 3), 7.0, device='cuda'); db3 = torch.full((c,), 7.0, device='cuda')
+    check(L.dbx_conv_wgrad_pool_dz(dt, C.byref(dyv), ptr(idx), c, C.byref(zv3), C.byref(xv), 3, 3, 1, c, c, ptr(dw3), ptr(db3), ptr(sc), 0, 1, stream_ptr()))
     torch.cuda.synchronize()
     assert float(dw1.abs().sum()) > 0 and float(db1.abs().sum()) > 0
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    assert torch.equal(dw1, dw3) and torch.equal(db1, db3)
+    assert torch.equal(tz3, tz)                                                       # the whole frame, halo zeros included
+    lo = (fz3.numel() - tz3.numel()) // 2
+    assert torch.equal(fz3[:lo], guard_before[:lo]) and torch.equal(fz3[lo + tz3.numel():], guard_before[lo + tz3.numel():])   # guard bands untouched
     # ... and the pair is the gradient torch computes through ReLU -> MaxPool2d on the same rounded operands
     zr = tz[:, 1:1 + h, 1:1 + w].permute(0, 3, 1, 2).float()
     xr = tx[:, 1:1 + h, 1:1 + w].permute(0, 3, 1, 2).float()
