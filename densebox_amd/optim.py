@@ -21,6 +21,7 @@ class SGD:
         self.guard = None          # int32[2] on the device: [last step id with a non-finite gradient, number of skipped steps]
         self._guard_flat = None
         self._guard_on = False
+        self._grads_in_flat = False
         self._step_id = 0
 
     def enable_guard(self, flat_grads, on=True):
@@ -31,6 +32,8 @@ class SGD:
         leaves a defined state.  `on=False` keeps the state but runs the plain update (bf16 / fp32 steps: their range is fp32's)."""
         if self.guard is None:
             self.guard = torch.zeros(2, dtype=torch.int32, device=flat_grads.device)
+        if self._guard_flat is not flat_grads:
+            self._key = None                              # (the "gradients live in the flat buffer" check is part of the cached table)
         self._guard_flat = flat_grads
         self._guard_on = bool(on)
 
@@ -60,6 +63,11 @@ class SGD:
         key = tuple((p.data_ptr(), gr.data_ptr()) for p, gr in zip(live, grads))
         dev = live[0].device
         if key != self._key:
+            # the guard scans the flat buffer: it only stands for this step when every gradient LIVES in it (a plain loss.backward() after
+            # DataParallel.close() hands out separate tensors; a stale inf in the flat buffer must not skip that step)
+            fl = self._guard_flat
+            self._grads_in_flat = fl is not None and all(
+                fl.data_ptr() <= gr.data_ptr() and gr.data_ptr() + 4 * gr.numel() <= fl.data_ptr() + 4 * fl.numel() for gr in grads)
             tab = []
             for p, gr in zip(live, grads):
                 assert p.dtype == torch.float32 and p.is_contiguous() and gr.dtype == torch.float32
@@ -71,7 +79,7 @@ class SGD:
         ptrs, sizes, mx = self._table
         with torch.no_grad():
             gw = None
-            if guarded:
+            if guarded and self._grads_in_flat:
                 self._step_id += 1
                 gw = self.guard
                 fl = self._guard_flat
