@@ -1311,20 +1311,21 @@ def test_heads_gen_16bit_kernels_equal_their_fp32_reference_forms_exactly(drop, 
 
 
 @pytest.mark.parametrize('dtn', ['bf16', 'f16'])
-@pytest.mark.parametrize('shape', [(3, 40, 72), (2, 24, 64), (5, 62, 90), (2, 240, 240)])
+@pytest.mark.parametrize('shape', [(3, 40, 72), (2, 24, 64), (5, 62, 90), (2, 240, 240), (2, 30, 70, 128)])
 def test_conv_wgrad_with_the_pooling_backward_as_dz_equals_the_two_calls(shape, dtn):
     """dbx_conv_wgrad_pool_dz (conv1_2's weight gradient reading pool1's backward from d_p1 + the arg-max nibbles, wgrad3x3_strip_kernel<T, true>)
     against dbx_maxpool2x2_bwd_idx into memory + dbx_conv_wgrad on that map: dW and db bitwise equal (same kernel, same operand bits) -- on
     activations quantised so that ties and all-zero windows (gate bit clear) occur, widths that leave a ragged last strip, and the real
     conv1_2 geometry."""
-    n, h, w = shape
+    n, h, w = shape[:3]
     c = 64
+    cx = shape[3] if len(shape) > 3 else 64                                           # (128 input channels: two ci tiles, the map is written by one of them)
     L = _lib.lib()
     dt, tdt = _lib.DTYPE_ID[dtn], TDT[dtn]
     g = torch.Generator(device='cpu').manual_seed(h * 7 + w)
     act = F.relu(torch.round(torch.randn(n, c, h, w, generator=g) * 2) / 2)          # the pooled layer's output (conv1_2 after its ReLU)
     dy = torch.randn(n, c, h // 2, w // 2, generator=g)
-    x = torch.randn(n, c, h, w, generator=g)                                          # conv1_2's input (conv1_1's output)
+    x = torch.randn(n, cx, h, w, generator=g)                                         # conv1_2's input (conv1_1's output)
     fa, ta, av = framed(act.cuda(), 1, tdt)
     fp, tp, pv = framed(torch.zeros(n, c, h // 2, w // 2), 0, tdt)
     idx = torch.zeros(L.dbx_maxpool_idx_bytes(n, h, w, c) + 16, dtype=torch.uint8, device='cuda')
@@ -1335,17 +1336,17 @@ def test_conv_wgrad_with_the_pooling_backward_as_dz_equals_the_two_calls(shape, 
     assert L.dbx_conv_wgrad_pool_dz_ok(dt, C.byref(zv), C.byref(xv), 3, 3) == 1
     check(L.dbx_maxpool2x2_bwd_idx(dt, ptr(idx), C.byref(dyv), C.byref(zv), 0, 1, stream_ptr()))
     sc = torch.empty(L.dbx_conv_wgrad_scratch_bytes(dt, C.byref(zv), C.byref(xv), 3, 3), dtype=torch.uint8, device='cuda')
-    dw1 = torch.full((c, c, 3, 3), 7.0, device='cuda'); db1 = torch.full((c,), 7.0, device='cuda')
-    dw2 = torch.full((c, c, 3, 3), 7.0, device='cuda'); db2 = torch.full((c,), 7.0, device='cuda')
-    check(L.dbx_conv_wgrad(dt, C.byref(zv), C.byref(xv), 3, 3, 1, c, c, ptr(dw1), ptr(db1), ptr(sc), 0, stream_ptr()))
+    dw1 = torch.full((c, cx, 3, 3), 7.0, device='cuda'); db1 = torch.full((c,), 7.0, device='cuda')
+    dw2 = torch.full((c, cx, 3, 3), 7.0, device='cuda'); db2 = torch.full((c,), 7.0, device='cuda')
+    check(L.dbx_conv_wgrad(dt, C.byref(zv), C.byref(xv), 3, 3, 1, c, cx, ptr(dw1), ptr(db1), ptr(sc), 0, stream_ptr()))
     zshape = View(None, n, h, w, 1, c, 0, c)                                          # the map is NOT handed over: shape only
-    check(L.dbx_conv_wgrad_pool_dz(dt, C.byref(dyv), ptr(idx), c, C.byref(zshape), C.byref(xv), 3, 3, 1, c, c, ptr(dw2), ptr(db2), ptr(sc), 0, 0, stream_ptr()))
+    check(L.dbx_conv_wgrad_pool_dz(dt, C.byref(dyv), ptr(idx), c, C.byref(zshape), C.byref(xv), 3, 3, 1, c, cx, ptr(dw2), ptr(db2), ptr(sc), 0, 0, stream_ptr()))
     # write_dz: the same call also leaves the un-pooled gradient map in memory (frame incl. its zero halo; here the destination starts as garbage)
     fz3, tz3, zv3 = framed(torch.full((n, c, h, w), 3.0), 1, tdt)
     tz3[:, 0] = 5.0; tz3[:, -1] = 5.0; tz3[:, :, 0] = 5.0; tz3[:, :, -1] = 5.0
     guard_before = fz3.clone()
-    dw3 = torch.full((c, c, 3, 3), 7.0, device='cuda'); db3 = torch.full((c,), 7.0, device='cuda')
-    check(L.dbx_conv_wgrad_pool_dz(dt, C.byref(dyv), ptr(idx), c, C.byref(zv3), C.byref(xv), 3, 3, 1, c, c, ptr(dw3), ptr(db3), ptr(sc), 0, 1, stream_ptr()))
+    dw3 = torch.full((c, cx, 3, 3), 7.0, device='cuda'); db3 = torch.full((c,), 7.0, device='cuda')
+    check(L.dbx_conv_wgrad_pool_dz(dt, C.byref(dyv), ptr(idx), c, C.byref(zv3), C.byref(xv), 3, 3, 1, c, cx, ptr(dw3), ptr(db3), ptr(sc), 0, 1, stream_ptr()))
     torch.cuda.synchronize()
     assert float(dw1.abs().sum()) > 0 and float(db1.abs().sum()) > 0
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
@@ -1356,7 +1357,7 @@ def test_conv_wgrad_with_the_pooling_backward_as_dz_equals_the_two_calls(shape, 
     # ... and the pair is the gradient torch computes through ReLU -> MaxPool2d on the same rounded operands
     zr = tz[:, 1:1 + h, 1:1 + w].permute(0, 3, 1, 2).float()
     xr = tx[:, 1:1 + h, 1:1 + w].permute(0, 3, 1, 2).float()
-    ref = torch.nn.grad.conv2d_weight(xr, (c, c, 3, 3), zr, padding=1)
+    ref = torch.nn.grad.conv2d_weight(xr, (c, cx, 3, 3), zr, padding=1)
     assert float((dw2 - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
     # odd extents, 3-channel-group mismatches: the query says no
     assert L.dbx_conv_wgrad_pool_dz_ok(dt, C.byref(View(None, n, h + 1, w, 1, c, 0, c)), C.byref(xv), 3, 3) == 0
