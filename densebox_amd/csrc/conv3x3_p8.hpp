@@ -237,6 +237,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8_kernel(const ConvArgs a, co
     auto stA = [&](int kt, int mh, unsigned dst) {
         bool nx; int chunk, tap;
         k_split(kt, nx, chunk, tap);
+#if defined(P8_ABL) && (P8_ABL & 8)
+        // lab, timing only (results are garbage): the A half-tiles of taps 1..8 are not staged -- an UPPER bound on what a halo-tile A operand
+        // (one staging per 64-channel chunk for all nine taps) could take out of the K loop.  The counted waits stay safe: fewer loads in flight.
+        if (NTAPS == 9 && tap != 0) return;
+#endif
         int toff = 0;
         if constexpr (NTAPS == 9) { const int ky = (tap * 11) >> 5, kx = tap - 3 * ky; toff = (ky * a.x_wp + kx) * pix_bytes; }
         const char* b = a.x + toff + chunk * 128;
@@ -616,6 +621,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_p8w_kernel(const ConvArgs a, c
     auto stA = [&](int kt, int mh, unsigned dst) {
         bool nx; int chunk, tap;
         k_split(kt, nx, chunk, tap);
+#if defined(P8_ABL) && (P8_ABL & 8)
+        // lab, timing only (results are garbage): the A half-tiles of taps 1..8 are not staged -- an UPPER bound on what a halo-tile A operand
+        // (one staging per 64-channel chunk for all nine taps) could take out of the K loop.  The counted waits stay safe: fewer loads in flight.
+        if (NTAPS == 9 && tap != 0) return;
+#endif
         int toff = 0;
         if constexpr (NTAPS == 9) { const int ky = (tap * 11) >> 5, kx = tap - 3 * ky; toff = (ky * a.x_wp + kx) * pix_bytes; }
         const char* b = a.x + toff + chunk * 128;
