@@ -1233,7 +1233,8 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
     }
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 acc[KJ][V / 2];
-    float bs[KJ], w[8][V], va[V], vb[V];
+    float bs[KJ], w[8][V];
+    f32x2 va[V / 2], vb[V / 2], w2[KJ][V / 2];
 #pragma unroll
     for (int j = 0; j < KJ; ++j) {
         bs[j] = 0.f;
@@ -1241,13 +1242,22 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
         for (int i = 0; i < V / 2; ++i) acc[j][i] = (f32x2){0.f, 0.f};
     }
 #pragma unroll
-    for (int i = 0; i < V; ++i) va[i] = vb[i] = 0.f;
+    for (int i = 0; i < V / 2; ++i) va[i] = vb[i] = (f32x2){0.f, 0.f};
     { int k; head2_load_w<V>(ha, hd, c0, active, w, k); }
     if (nostore) {                                                      // the consumers generate d_hid with W2 in the compute dtype (GenHid): the same values here
 #pragma unroll
         for (int j = 0; j < KJ; ++j)
 #pragma unroll
             for (int i = 0; i < V; ++i) w[j][i] = to_f32(from_f32<T>(w[j][i]));
+    }
+    // round 6: the weights as pairs (the products run as v_pk_fma_f32: half the issue slots of the eight v_fma_mix per d_out channel) with the
+    // dropout scale folded in (x 2 is exact: sum_j g_j (2 w_j) has the bits of 2 sum_j g_j w_j), so a kept element needs no multiply
+    {
+        const float dscale = (mask || use_hash) ? 2.f : 1.f;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j)
+#pragma unroll
+            for (int i = 0; i < V / 2; ++i) w2[j][i] = (f32x2){w[j][2 * i] * dscale, w[j][2 * i + 1] * dscale};
     }
     // addresses = uniform row base (scalar registers) + a per-lane 32-bit element offset fixed for the whole walk (geo_pix per pixel is a
     // 64-bit vector multiply: quarter-rate instructions)
@@ -1286,11 +1296,11 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
         }
         pend = 0;
     };
-    auto finalize = [&](int iy, const float (&v)[V]) {          // source row iy of image n is complete
+    auto finalize = [&](int iy, const f32x2 (&v)[V / 2]) {      // source row iy of image n is complete
         float* buf = s_v + (wr % (2 * NB)) * (PW * CS);
         if (active) {
-            *(f32x4*)&buf[pl * CS + ch * V] = (f32x4){v[0], v[1], v[2], v[3]};
-            *(f32x4*)&buf[pl * CS + ch * V + 4] = (f32x4){v[4], v[5], v[6], v[7]};
+            *(f32x4*)&buf[pl * CS + ch * V] = (f32x4){v[0].x, v[0].y, v[1].x, v[1].y};
+            *(f32x4*)&buf[pl * CS + ch * V + 4] = (f32x4){v[2].x, v[2].y, v[3].x, v[3].y};
         }
         if (pend == 0) pend_iy = iy;
         ++wr; ++pend;
@@ -1327,15 +1337,15 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
                 while (y0 > cur) {                                      // (uniform) the walk left source row `cur`
                     finalize(cur, va);
 #pragma unroll
-                    for (int i = 0; i < V; ++i) { va[i] = vb[i]; vb[i] = 0.f; }
+                    for (int i = 0; i < V / 2; ++i) { va[i] = vb[i]; vb[i] = (f32x2){0.f, 0.f}; }
                     ++cur;
                 }
                 const float wa = (y0 == cur ? ly0 : 0.f) + (y1 == cur ? ly1 : 0.f);
                 const float wb = (y0 == cur + 1 ? ly0 : 0.f) + (y1 == cur + 1 ? ly1 : 0.f);
                 {
-                    float o[V];                                       // same arithmetic and order as head2_dgrad_kernel (its terms past k are + 0)
+                    f32x2 o2[V / 2];                                  // same arithmetic and order as head2_dgrad_kernel (its terms past k are + 0; x 2 folded into w2)
 #pragma unroll
-                    for (int i = 0; i < V; ++i) o[i] = 0.f;
+                    for (int i = 0; i < V / 2; ++i) o2[i] = (f32x2){0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < KJ; ++j) {
                         bs[j] += gj[j];
@@ -1343,36 +1353,43 @@ __global__ __launch_bounds__(256, 2) void head2_backward_up_kernel(FrameGeo dout
 #pragma unroll
                         for (int i = 0; i < V / 2; ++i) acc[j][i] = g2 * (f32x2){h[2 * i], h[2 * i + 1]} + acc[j][i];
 #pragma unroll
-                        for (int i = 0; i < V; ++i) o[i] = fmaf(gj[j], w[j][i], o[i]);
+                        for (int i = 0; i < V / 2; ++i) o2[i] = g2 * w2[j][i] + o2[i];
                     }
+                    float o[V];
+#pragma unroll
+                    for (int i = 0; i < V / 2; ++i) { o[2 * i] = o2[i].x; o[2 * i + 1] = o2[i].y; }
                     const long long pc0 = ((long long)n * H + oy) * W;          // (uniform) index of the row's first pixel
                     if (mask) {
                         unsigned char mb[V];
                         *(u32x2*)mb = *(const u32x2*)(mask + (size_t)pc0 * mask_ld + lo_mask);
 #pragma unroll
-                        for (int i = 0; i < V; ++i) o[i] = mb[i] ? o[i] * 2.f : 0.f;
+                        for (int i = 0; i < V; ++i) o[i] = mb[i] ? o[i] : 0.f;
                     } else if (use_hash) {
+                        // one hash covers the chunk's eight channels (they lie in one 32-channel block); a dropped element is cleared by ANDing
+                        // with its keep bit, sign-extended
+                        const unsigned kb8 = dbx_drop_hash32(drop_seed, (unsigned)pc0 + (unsigned)px, (unsigned)(hd * 512 + c0) >> 5) >> ((unsigned)c0 & 31u);
 #pragma unroll
-                        for (int q = 0; q < V / 4; ++q) {
-                            const unsigned kb = dbx_drop_bits4(drop_seed, (unsigned)pc0 + (unsigned)px, (unsigned)(hd * 512 + c0) / 4 + q);
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) o[4 * q + i] = (kb >> i & 1u) ? o[4 * q + i] * 2.f : 0.f;
-                        }
+                        for (int i = 0; i < V; ++i)
+                            o[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, o[i]) & ((int)(kb8 << (31 - i)) >> 31));
                     }
                     u32x4 raw;
                     T* oe = (T*)&raw;
 #pragma unroll
                     for (int i = 0; i < V; ++i) oe[i] = from_f32<T>(o[i]);
                     if (owner && !nostore) *(u32x4*)((T*)dhid.base + row_of(dhid, n, oy) + lo_dhid) = raw;
+                    const f32x2 wa2 = {wa, wa}, wb2 = {wb, wb};
 #pragma unroll
-                    for (int i = 0; i < V; ++i) { const float dv = to_f32(oe[i]); va[i] = fmaf(wa, dv, va[i]); vb[i] = fmaf(wb, dv, vb[i]); }
+                    for (int i = 0; i < V / 2; ++i) {
+                        const f32x2 dv = {to_f32(oe[2 * i]), to_f32(oe[2 * i + 1])};
+                        va[i] = wa2 * dv + va[i]; vb[i] = wb2 * dv + vb[i];
+                    }
                 }
                 if (++oy == H) {                                        // (uniform) the image is done: its last source rows, next image
                     finalize(cur, va);
                     if (cur + 1 < dg.h) finalize(cur + 1, vb);
                     if (pend) flush();
 #pragma unroll
-                    for (int i = 0; i < V; ++i) va[i] = vb[i] = 0.f;
+                    for (int i = 0; i < V / 2; ++i) va[i] = vb[i] = (f32x2){0.f, 0.f};
                     cur = 0; oy = 0; n += G;
                 }
             }
