@@ -1485,6 +1485,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_kernel(const WgradArgs a) {
 // here) straight from its sources instead: the pooled gradient d_p1 (118 MB) and the arg-max nibbles (30 MB).  The dz row of a step is
 // register-staged already; a thread's chunk (eight channels of one pixel) becomes the pooled pixel's chunk ANDed with the eight 16-bit
 // masks "this pixel is the window's arg-max and the maximum was positive" decoded from one dword of nibbles (22 VALU instructions).
+#ifndef STRIP_MI
+#define STRIP_MI 4
+#endif
 template <typename T, bool POOLDZ = false>
 __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs a) {
     static_assert(sizeof(T) == 2, "16-bit tiles");
@@ -1496,7 +1499,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;                           // wave tile 32(co) x 32(ci)
+    // wave tile: (16 MI) co x (16 NI) ci with MI NI = 4.  Round 6: 64 x 16 (MI 4: every wave reads all four dz fragments and ONE band run per ky:
+    // 17 transposed LDS reads per 36 MFMAs) instead of 32 x 32 (MI 2: 22 reads) -- the kernel is bound by those reads (STRIP_MI=2: the old tiling)
+    constexpr int MI = STRIP_MI, NI = 4 / MI;
+    static_assert(MI == 2 || MI == 4, "wave tiling");
+    const int wm = MI == 4 ? 0 : wave >> 1, wn = MI == 4 ? wave : wave & 1;
     int t, split;
     wg_tile_split(a.tiles_co * a.tiles_ci, a.nsplit, t, split);
     const int tile_ci = t % a.tiles_ci, tile_co = t / a.tiles_ci;
@@ -1513,13 +1520,13 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
     u32x4 areg[2], breg[2][2];                                         // two register sets: loads run TWO steps ahead
     unsigned nreg[2] = {0u, 0u};                                        // POOLDZ: the chunk's eight arg-max nibbles
 
-    f32x4 acc[9][2][2];
+    f32x4 acc[9][MI][NI];
 #pragma unroll
     for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) acc[t9][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int ni = 0; ni < NI; ++ni) acc[t9][mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float bsum[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
@@ -1614,28 +1621,29 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
             { const int r2 = s + 2 < nsteps ? s + 2 : nsteps - 1; gload_a(SET, r2); gload_b(SET, r2 + 2 + a.shift0); }   // (clamped: no branch)
             const char* Ab = As + buf * A_BYTES;
             const int r0 = 8 * g + rsub;
-            u32x4 af[2];
+            u32x4 af[MI];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int cbyte = (wm * 32 + mi * 16) * 2 + csub;
+            for (int mi = 0; mi < MI; ++mi) {
+                const int cbyte = (wm * 16 * MI + mi * 16) * 2 + csub;
                 const u32x2 lo = trd(Ab + swz16<64>(r0, cbyte)), hi = trd(Ab + swz16<64>(r0 + 4, cbyte));
                 af[mi] = (u32x4){lo.x, lo.y, hi.x, hi.y};
             }
             struct Run { u32x2 c0, c1, c2; };
             auto rdRun = [&](int v) {
-                const int cbyte = (wn * 32 + (v & 1) * 16) * 2 + csub, rb = ((s + a.shift0 + (v >> 1) + 4) & 3) * BROWS + r0;
+                const int cbyte = (wn * 16 * NI + (v % NI) * 16) * 2 + csub, rb = ((s + a.shift0 + (v / NI) + 4) & 3) * BROWS + r0;
                 Run r;
                 r.c0 = trd(Bs + swz16<64>(rb, cbyte)); r.c1 = trd(Bs + swz16<64>(rb + 4, cbyte)); r.c2 = trd(Bs + swz16<64>(rb + 8, cbyte));
                 return r;
             };
             Run run[2];
             run[0] = rdRun(0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * MI + 3, 0);
+            constexpr int NV = 3 * NI;
 #pragma unroll
-            for (int v = 0; v < 6; ++v) {
-                const int ky = v >> 1, ni = v & 1;
+            for (int v = 0; v < NV; ++v) {
+                const int ky = v / NI, ni = v % NI;
                 const Run c = run[v & 1];
-                if (v < 5) run[(v + 1) & 1] = rdRun(v + 1);
+                if (v < NV - 1) run[(v + 1) & 1] = rdRun(v + 1);
                 u32x4 bf[3];
                 bf[0] = (u32x4){c.c0.x, c.c0.y, c.c1.x, c.c1.y};
                 bf[1] = (u32x4){__builtin_amdgcn_alignbit(c.c0.y, c.c0.x, 16), __builtin_amdgcn_alignbit(c.c1.x, c.c0.y, 16),
@@ -1644,15 +1652,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-                    for (int mi = 0; mi < 2; ++mi) {
+                    for (int mi = 0; mi < MI; ++mi) {
                         f32x4& cc = acc[ky * 3 + kx][mi][ni];
                         if constexpr (DType<T>::id == DBX_F16)
                             cc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, bf[kx]), __builtin_bit_cast(f16x8, af[mi]), cc, 0, 0, 0);
                         else
                             cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, bf[kx]), __builtin_bit_cast(bf16x8, af[mi]), cc, 0, 0, 0);
                     }
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    if (v < 5) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MI, 0);
+                    if (v < NV - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
             // the new x row goes to the slot of row s + shift0 - 1 (dead since the previous step's barrier), dz to the other buffer
@@ -1667,14 +1675,14 @@ __global__ __launch_bounds__(256, 2) void wgrad3x3_strip_kernel(const WgradArgs 
 
     {
         float* P = a.partial + (((long long)split * a.co_pad) * 9) * a.ci_pad;
-        const int co_b = tile_co * 64 + wm * 32 + (lane & 15);
-        const int ci_b = tile_ci * 64 + wn * 32 + (lane >> 4) * 4;
+        const int co_b = tile_co * 64 + wm * 16 * MI + (lane & 15);
+        const int ci_b = tile_ci * 64 + wn * 16 * NI + (lane >> 4) * 4;
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9)
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
                     *(f32x4*)(P + ((long long)(co_b + mi * 16) * 9 + t9) * a.ci_pad + ci_b + ni * 16) = acc[t9][mi][ni];
     }
     if (do_bias) {
